@@ -1,0 +1,265 @@
+/*
+ * rt_hip.h — C-ABI of the MI355X path-tracing hot path (librt_hip.so).
+ *
+ * The reference (charlesrw1/Raytracing) has no plugin/FFI seam: the GPU path
+ * slots in behind plain C++ calls inside one executable.  Every entry point
+ * below names the reference call it replaces (file:line relative to the
+ * reference tree).  Plain C, plain pointers and sizes, no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or an RT_ERR_* code; the message for
+ *     the calling thread's last failure is rt_last_error().  (The reference
+ *     reports errors with bool/nullptr + printf: Scene.cpp:203-206,
+ *     BVH.cpp:138-141.)
+ *   - one rt_scene per GPU; calls on one handle are not re-entrant; different
+ *     handles may be driven from different host threads.
+ *   - "host" pointers are ordinary malloc'ed memory, "device" pointers are
+ *     HBM addresses on the scene's GPU (e.g. a torch tensor's data_ptr()).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID 1   /* bad argument / inconsistent description        */
+#define RT_ERR_NO_DEVICE 2 /* no usable HIP device                           */
+#define RT_ERR_HIP 3       /* a HIP runtime call failed (see rt_last_error)  */
+#define RT_ERR_LIMIT 4     /* a documented size limit was exceeded           */
+
+/* ---- plain data ------------------------------------------------------- */
+
+typedef struct rt_scene rt_scene; /* opaque: one uploaded scene on one GPU */
+
+/* Ray: Math.h:622-633 (pos, dir), 24 B. */
+typedef struct rt_ray {
+    float o[3];
+    float d[3];
+} rt_ray;
+
+/* Closest-hit record.  tri = index into the mesh's triangle array
+ * (Mesh.h:15-19 order), -1 on a miss; (u,v) = bary_out.x/.y of
+ * IntersectTriRay2 (Object.h:245-264); t as accepted at Object.h:312-315. */
+typedef struct rt_hit {
+    int32_t tri;
+    float t;
+    float u;
+    float v;
+} rt_hit;
+
+/* One inner BVH node flattened as a 64-byte child-pair record: the two
+ * adjacent children (BVH.cpp:122-125 allocates left, left+1) of a branch
+ * node (BVH.h:15-21), so one traversal step (Object.h:322-326) reads one
+ * aligned 64-byte line.
+ * child ref >= 0 : index of the child's own pair record (child is a branch)
+ * child ref <  0 : child is a leaf; its first triangle slot is ~ref         */
+typedef struct rt_bvh_pair {
+    float lmin[3];
+    float lmax[3];
+    float rmin[3];
+    float rmax[3];
+    int32_t lref;
+    int32_t rref;
+    int32_t reserved[2];
+} rt_bvh_pair;
+
+#define RT_TRI_LEAF_END 0x80000000u
+
+/* One triangle in leaf order (slot k holds triangle BVH::indicies[k],
+ * BVH.h:32), pre-differenced exactly as IntersectTriRay2 does
+ * (edge1 = v1 - v0, edge2 = v2 - v0: Object.h:247-248), 48 B.
+ * tri_id: original triangle index, bit 31 (RT_TRI_LEAF_END) set on the last
+ * triangle of its leaf.  material: MeshTriangle::materialIndex (Mesh.h:18).
+ * light: index into rt_scene_desc.lights or -1. */
+typedef struct rt_tri {
+    float v0[3];
+    uint32_t tri_id;
+    float e1[3];
+    int32_t material;
+    float e2[3];
+    int32_t light;
+} rt_tri;
+
+/* Shading normals of slot k's three corners (Vertex::normal, Mesh.h:8-13;
+ * interpolated at Object.h:351-353), 48 B. */
+typedef struct rt_tri_normals {
+    float n0[3];
+    float pad0;
+    float n1[3];
+    float pad1;
+    float n2[3];
+    float pad2;
+} rt_tri_normals;
+
+/* Material table entry (Material.h / Material.cpp classes flattened to a tag
+ * + parameters), 80 B. */
+enum {
+    RT_MAT_MATTE = 0,            /* MatteMaterial      Material.h:64-92   c0 = albedo                  */
+    RT_MAT_MICROFACET_GGX = 1,   /* Microfacet         Material.cpp:4-109 s0 = roughness               */
+    RT_MAT_MICROFACET_BECKMANN = 2, /* (new, no reference arithmetic)     s0 = roughness               */
+    RT_MAT_EMISSIVE = 3,         /* EmissiveMaterial   Material.h:274-284 c0 = emit                    */
+    RT_MAT_DISNEY_DIFFUSE = 4,   /* Material.cpp:114-153  c0 albedo, s0 roughness, s1 subsurface       */
+    RT_MAT_DISNEY_METAL = 5,     /* Material.cpp:160-252  c0 albedo, s0 roughness, s1 anisotropic      */
+    RT_MAT_DISNEY_CLEARCOAT = 6, /* Material.cpp:256-329  s0 clearcoat_gloss                           */
+    RT_MAT_DISNEY_GLASS = 7,     /* Material.cpp:333-460  c0 albedo, s0 roughness, s1 aniso, s2 eta    */
+    RT_MAT_ROUGH_DIELECTRIC = 8, /* Material.cpp:463-542  c0 refl, c1 trans, s0 eta, s1 roughness      */
+    RT_MAT_DISNEY_SHEEN = 9,     /* Material.cpp:545-567  c0 base, s0 sheen_tint                       */
+    RT_MAT_DISNEY_UBER = 10,     /* Material.cpp:571-722  c0 base, s[0..12] = Material.h:184-196 order */
+    RT_MAT_GLASS = 11            /* GlassMaterial      Material.h:240-273 s0 = index_r                 */
+};
+typedef struct rt_material {
+    int32_t type;
+    float c0[3];
+    float c1[3];
+    float s[13];
+} rt_material;
+
+enum { RT_LIGHT_RECT = 0, RT_LIGHT_TRIMESH = 1 };
+
+/* Area light.  RECT restates an Instance(Rectangle, EmissiveMaterial, mat4)
+ * pushed into Scene::lights (Object.h:61-135,364-423; main.cpp:801-813).
+ * TRIMESH (extension: the reference cannot sample mesh emitters) is a range of
+ * rt_emissive_tri entries with an area CDF. */
+typedef struct rt_light {
+    int32_t kind;
+    int32_t material; /* index of the emissive material                      */
+    int32_t first;    /* TRIMESH: first entry in emissive_tris               */
+    int32_t count;    /* TRIMESH: number of entries                          */
+    float area;       /* Instance::get_area (Object.h:404-407) / mesh area   */
+    float n[3];       /* RECT: Rectangle N, T, B (model space)               */
+    float t[3];
+    float b[3];
+    float hu;         /* RECT: half side lengths u, v (Object.h:68-69)       */
+    float hv;
+    float m[16];      /* RECT: model-to-world, column-major (Math.h:338-347) */
+    float inv_m[16];  /* RECT: world-to-model                                */
+} rt_light;
+
+typedef struct rt_emissive_tri {
+    int32_t slot; /* triangle slot (leaf order) */
+    float cdf;    /* cumulative area fraction up to and including this entry */
+} rt_emissive_tri;
+
+/* Everything rt_scene_create copies to HBM once ("upload once"); the caller
+ * keeps ownership of every host array. */
+typedef struct rt_scene_desc {
+    int32_t root_ref;              /* child-ref encoding of BVH node 0       */
+    int64_t n_pairs;
+    const rt_bvh_pair* pairs;
+    int64_t n_tris;
+    const rt_tri* tris;
+    const rt_tri_normals* normals;
+    int32_t n_materials;
+    const rt_material* materials;
+    int32_t n_lights;
+    const rt_light* lights;
+    int32_t n_emissive_tris;
+    const rt_emissive_tri* emissive_tris;
+    /* EnviormentLight (main.cpp:88-193): RGB_32f lat-long image, its flat CDF
+     * (build_cdf, main.cpp:97-120) and total_sum; offset = degrees/360. */
+    int32_t env_w;
+    int32_t env_h;
+    const float* env_rgb;
+    const float* env_cdf;
+    float env_total;
+    float env_offset;
+} rt_scene_desc;
+
+enum { RT_FILTER_GAUSSIAN = 0, RT_FILTER_BOX = 1 };
+
+/* Camera (Scene.h:10-81): raster_to_world and camera_pos as built by the
+ * constructor, plus the pixel filter sampled at ray generation
+ * (Filter.h:12-42; param = stddev or width). */
+typedef struct rt_camera {
+    float raster_to_world[16];
+    float pos[3];
+    int32_t filter;
+    float filter_param;
+} rt_camera;
+
+#define RT_RENDER_CLEAR 1u      /* zero radiance_sum before accumulating      */
+#define RT_RENDER_DEVICE_OUT 2u /* radiance_sum is a device pointer           */
+#define RT_RENDER_TIMING 4u     /* bracket every kernel with HIP events       */
+
+/* Options (main.cpp:836-850) + the sample window this call renders.
+ * Sample i of pixel (x,y) is hammersley_2d(i, spp_total) (Utils.h:148-151);
+ * this call renders i in [spp_begin, spp_begin + spp_count) for pixels in
+ * [x0,x1) x [y0,y1) of a width x height raster. */
+typedef struct rt_options {
+    int32_t width;
+    int32_t height;
+    int32_t spp_begin;
+    int32_t spp_count;
+    int32_t spp_total;
+    int32_t max_depth;     /* MAX_DEPTH, main.cpp:33,335 */
+    int32_t x0, y0, x1, y1;
+    uint32_t seed;
+    int32_t spp_per_pass;  /* samples per pixel traced together in one wavefront pass; 0 = auto */
+    uint32_t flags;
+} rt_options;
+
+typedef struct rt_stats {
+    uint64_t rays_closest; /* closest-hit queries issued (main.cpp:338)      */
+    uint64_t rays_shadow;  /* shadow queries issued (main.cpp:250,281)       */
+    uint64_t paths;        /* camera samples started                         */
+    uint64_t launches_closest;
+    uint64_t launches_shadow;
+    float ms_total;        /* whole call, HIP events on the scene's stream   */
+    float ms_generate;     /* per kernel, only with RT_RENDER_TIMING         */
+    float ms_closest;
+    float ms_shade;
+    float ms_shadow;
+    float ms_accumulate;
+} rt_stats;
+
+/* ---- entry points ----------------------------------------------------- */
+
+const char* rt_last_error(void);
+
+/* Number of HIP devices visible (0 when none). */
+int rt_device_count(void);
+
+/* Replaces Scene::build_top_level_bvh + the per-mesh BVH ownership
+ * (Scene.cpp:6-15, Object.cpp:24-29): uploads the flattened scene to
+ * `device` and returns an opaque handle. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Replaces bool Scene::closest_hit(Ray, Intersection*) const
+ * (Scene.cpp:17-77 over TriangleMesh::intersect, Object.h:273-357) for a
+ * batch of n rays; host pointers. */
+int rt_trace_closest(rt_scene* scene, const rt_ray* rays, int64_t n, rt_hit* hits);
+
+/* Replaces Scene::trace_scene(Ray, 0, tmax, &tmp) used as a boolean
+ * occlusion test (Scene.h:113-129; call sites main.cpp:250,281) — what the
+ * declared-but-undefined Scene::any_hit (Scene.h:133) was to be.
+ * occluded[i] = 1 if any triangle is hit with 1e-4 < t <= tmax[i]. */
+int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* tmax, int64_t n,
+                 uint8_t* occluded);
+
+/* Replaces the body of Renderer::render_image (main.cpp:950-1005): for every
+ * pixel of the tile and every sample of the window, generate the camera ray
+ * (Scene.h:61-75), run get_ray_color (main.cpp:325-441) as a wavefront
+ * (generate / closest-hit / shade+NEE / shadow / accumulate kernels) and add
+ * the NaN-guarded sample (main.cpp:984-987) into radiance_sum[(y*width+x)*3],
+ * y in raster order (the flip of main.cpp:990 happens in rt_resolve). */
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
+              float* radiance_sum, rt_stats* stats);
+
+/* Replaces Renderer::add_to_buffer (main.cpp:865-877) for the whole image:
+ * 1/spp, pow(1/gamma), clamp*255, row H-y-1.  Host pointers. */
+int rt_resolve(rt_scene* scene, const float* radiance_sum, int32_t width, int32_t height,
+               int32_t spp, float gamma, uint8_t* rgb_out);
+
+/* Blocks until all work queued on the scene's stream has finished. */
+int rt_scene_sync(rt_scene* scene);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,813 @@
+// rt_device.h — device-side math, random stream, BVH traversal and material
+// functions for the gfx950 wavefront path tracer.  Included only by rt_hip.hip.
+//
+// Arithmetic notes (bit-exactness of hit indices, SURVEY §7 "hard parts"):
+//   * the file is compiled with -ffp-contract=off: no FMA is formed from a*b+c;
+//   * fmin_sel/fmax_sel are the select forms of the reference's Math.h:17-24,
+//     not v_min_f32/v_max_f32 (those differ when the SECOND operand is NaN);
+//   * 1.f/dir is an IEEE division (hipcc's default correctly-rounded fp32
+//     divide), vec3/float is a reciprocal multiply (Math.h:193-200).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_hip.h"
+
+#define RT_BLOCK 256        // threads per workgroup = 4 wave64
+#define RT_SHORT_STACK 16   // traversal stack entries per lane kept in LDS
+#define RT_STACK_TOTAL 64   // reference stack capacity (Object.h:275)
+
+#define RT_DEV __device__ __forceinline__
+
+namespace rtd {
+
+constexpr float kPi = 3.1415926536f; // Math.h:9 narrowed to float
+
+RT_DEV float fmax_sel(float a, float b) { return (a > b) ? a : b; }
+RT_DEV float fmin_sel(float a, float b) { return (a < b) ? a : b; }
+RT_DEV float clampf(float x, float lo, float hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
+
+struct V3 {
+    float x, y, z;
+    RT_DEV V3() {}
+    RT_DEV V3(float a, float b, float c) : x(a), y(b), z(c) {}
+    RT_DEV explicit V3(float e) : x(e), y(e), z(e) {}
+    RT_DEV explicit V3(const float* p) : x(p[0]), y(p[1]), z(p[2]) {}
+    RT_DEV explicit V3(const float4& q) : x(q.x), y(q.y), z(q.z) {}
+};
+RT_DEV V3 operator-(const V3& a) { return V3(-a.x, -a.y, -a.z); }
+RT_DEV V3 operator-(const V3& a, const V3& b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 operator+(const V3& a, const V3& b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 operator*(const V3& a, const V3& b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 operator*(float t, const V3& v) { return V3(t * v.x, t * v.y, t * v.z); }
+RT_DEV V3 operator*(const V3& v, float t) { return V3(v.x * t, v.y * t, v.z * t); }
+RT_DEV V3 operator/(const V3& v, float t) { return (1.f / t) * v; }
+RT_DEV float dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(const V3& u, const V3& v) { return V3(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
+RT_DEV float len2(const V3& v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+RT_DEV float len(const V3& v) { return sqrtf(len2(v)); }
+RT_DEV V3 normalize(const V3& v) { return v / len(v); }
+RT_DEV float luminance(const V3& c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; }
+RT_DEV float4 pack(const V3& v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+// ------------------------------------------------------------------ random
+// Counter-based stream keyed by (pixel, sample, seed); specified in DESIGN.md
+// and restated independently by the oracle.
+RT_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+RT_DEV uint32_t rng_key(uint32_t pixel, uint32_t sample, uint32_t seed) {
+    uint32_t k = mix32(pixel * 0x9E3779B1u + seed);
+    return mix32(k ^ (sample * 0x85EBCA77u + 0x165667B1u));
+}
+struct Rng {
+    uint32_t key, ctr;
+    RT_DEV float next() { return (float)(mix32(key + (ctr++) * 0xC2B2AE3Du) >> 8) * 5.9604644775390625e-08f; }
+};
+
+// --------------------------------------------------------------- traversal
+struct SceneView {
+    const float4* pairs;   // 4 x float4 per rt_bvh_pair
+    const float4* tris;    // 3 x float4 per rt_tri
+    const float4* normals; // 3 x float4 per rt_tri_normals
+    const rt_material* materials;
+    const rt_light* lights;
+    const rt_emissive_tri* emissive;
+    const float* env_rgb;
+    const float* env_cdf;
+    int32_t root_ref;
+    int32_t n_lights;
+    int32_t env_w, env_h;
+    float env_total, env_offset;
+};
+
+// Bounds::intersect, Math.h:755-770
+RT_DEV bool slab(const V3& bmin, const V3& bmax, const V3& o, const V3& inv, float& tnear_out) {
+    V3 t0 = (bmin - o) * inv;
+    V3 t1 = (bmax - o) * inv;
+    float ax = fmin_sel(t0.x, t1.x), ay = fmin_sel(t0.y, t1.y), az = fmin_sel(t0.z, t1.z);
+    float bx = fmax_sel(t0.x, t1.x), by = fmax_sel(t0.y, t1.y), bz = fmax_sel(t0.z, t1.z);
+    float tnear = fmax_sel(fmax_sel(ax, ay), az);
+    float tfar = fmin_sel(fmin_sel(bx, by), bz);
+    tnear_out = tnear;
+    return !(tnear > tfar || tfar < 0.f);
+}
+
+// Closest-hit (ANY = false: TriangleMesh::intersect, Object.h:273-344) or
+// boolean occlusion (ANY = true: trace_scene as used at main.cpp:250,281).
+// One ray per lane; the traversal stack keeps its first RT_SHORT_STACK entries
+// in LDS (column `lds[entry * RT_BLOCK]`, conflict-free across lanes) and spills
+// deeper entries to private memory.  Visit order, culling rule (`dist < t`, not
+// re-tested at pop) and the accept-on-equal-t rule are the reference's.
+template <bool ANY>
+RT_DEV bool traverse(const SceneView& sc, const V3& o, const V3& d, float tmax, int* lds, int& hit_slot, float& hit_t,
+                     float& hit_u, float& hit_v) {
+    int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
+    int sp = 0;
+    const V3 inv(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    float t = INFINITY;
+    int cur = sc.root_ref;
+    hit_slot = -1;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* p = sc.pairs + 4 * (size_t)cur;
+            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+            float ld, rd;
+            bool lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), o, inv, ld);
+            bool rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), o, inv, rd);
+            lh = lh && ld < t;
+            rh = rh && rd < t;
+            const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
+            if (lh && rh) {
+                const bool left_first = ld < rd; // ties visit the right child first (Object.h:329-336)
+                const int far = left_first ? rref : lref;
+                cur = left_first ? lref : rref;
+                if (sp < RT_SHORT_STACK) lds[sp * RT_BLOCK] = far;
+                else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
+                sp++;
+                continue;
+            }
+            if (lh) { cur = lref; continue; }
+            if (rh) { cur = rref; continue; }
+        } else {
+            int slot = ~cur;
+            bool last;
+            do {
+                const float4* tp = sc.tris + 3 * (size_t)slot;
+                const float4 a = tp[0], b = tp[1], c = tp[2];
+                last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
+                // IntersectTriRay2, Object.h:245-264 (edges pre-differenced by the host)
+                const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
+                const V3 h = cross(d, e2);
+                const float det = dot(e1, h);
+                // `a > -1e-7 && a < 1e-7` is written in double in the reference; float(1e-7) is the
+                // smallest float above the double 1e-7, so the fp32 compare accepts the same set.
+                if (!(det > -1e-7f && det < 1e-7f)) {
+                    const float f = 1.f / det;
+                    const V3 s = o - v0;
+                    const float u = f * dot(s, h);
+                    if (!(u < 0.f || u > 1.f)) {
+                        const V3 q = cross(s, e1);
+                        const float v = f * dot(d, q);
+                        if (!(v < 0.f || u + v > 1.f)) {
+                            const float tt = f * dot(e2, q);
+                            // Object.h:260 and 309-315 with tmin = 0
+                            if (tt > 0.0001f && !(tt > tmax) && !(tt < 0.f)) {
+                                tmax = tt;
+                                t = tt;
+                                hit_slot = slot;
+                                hit_t = tt;
+                                hit_u = u;
+                                hit_v = v;
+                                if (ANY) return true;
+                            }
+                        }
+                    }
+                }
+                slot++;
+            } while (!last);
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
+    }
+    return hit_slot >= 0;
+}
+
+// ---------------------------------------------------------------- shading
+RT_DEV void onb(const V3& N, V3& T, V3& B) { // Utils.h:53-59
+    V3 up(0.f, 0.f, 1.f);
+    if (fabsf(N.z) > 0.999f) up = V3(1.f, 0.f, 0.f);
+    T = normalize(cross(up, N));
+    B = cross(N, T);
+}
+RT_DEV V3 reflect(const V3& v, const V3& n) { return v - (2.f * dot(v, n)) * n; } // Utils.h:85-88
+RT_DEV V3 refract(const V3& uv, const V3& n, float eta) {                         // Utils.h:89-95
+    float theta = fmin_sel(dot(-uv, n), 1.0f);
+    V3 perp = eta * (uv + theta * n);
+    V3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * n;
+    return perp + par;
+}
+RT_DEV float pow5(float x) { return powf(x, 5.f); }
+RT_DEV float schlick_reflectance(float cosine, float ref_idx) { // Utils.h:96-101
+    float r0 = (1.f - ref_idx) / (1.f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.f - r0) * pow5(1.f - cosine);
+}
+RT_DEV float power_heuristic(float a, float b) { // Utils.h:130-136
+    float denom = a * a + b * b;
+    if (fabsf(denom) < 0.0001f) return 0.f;
+    return (a * a) / denom;
+}
+RT_DEV V3 cosine_sample(Rng& r) { // Utils.h:70-83
+    float r1 = r.next();
+    float r2 = r.next();
+    float phi = 2.f * kPi * r1;
+    float ct = sqrtf(1.f - r2);
+    float st = sqrtf(r2);
+    return V3(cosf(phi) * st, sinf(phi) * st, ct);
+}
+
+struct Surf { // Intersection, Def.h:11-40
+    V3 point, normal;
+    bool front_face;
+};
+struct Scatter {
+    V3 origin, dir, f;
+    float pdf;
+};
+
+// ---- GGX / Beckmann Microfacet (Material.cpp:4-109; Beckmann D is new)
+RT_DEV float ggx_D(const V3& N, const V3& H, float alpha) {
+    float ndh = fmax_sel(dot(H, N), 0.f);
+    if (ndh <= 0.f) return 0.f;
+    float half_angle = acosf(ndh);
+    float a2 = alpha * alpha;
+    float tn = tanf(half_angle);
+    float inner = a2 + tn * tn;
+    float n2 = ndh * ndh;
+    float denom = kPi * (n2 * n2) * (inner * inner);
+    if (denom <= 0.f) return 0.f;
+    return a2 / denom;
+}
+RT_DEV float beckmann_D(const V3& N, const V3& H, float alpha) {
+    float ndh = fmax_sel(dot(H, N), 0.f);
+    if (ndh <= 0.f) return 0.f;
+    float c2 = ndh * ndh;
+    float a2 = alpha * alpha;
+    float t2 = (1.f - c2) / c2;
+    float denom = kPi * a2 * c2 * c2;
+    if (denom <= 0.f) return 0.f;
+    return expf(-t2 / a2) / denom;
+}
+RT_DEV V3 microfacet_sample_h(const V3& N, float alpha, bool beckmann, Rng& r) { // Material.cpp:14-30
+    float r1 = r.next();
+    float r2 = r.next();
+    float theta_m = beckmann ? atanf(sqrtf(-(alpha * alpha) * logf(1.f - r1))) : atanf((alpha * sqrtf(r1)) / sqrtf(1.f - r1));
+    float phi = 2.f * kPi * r2;
+    float st = sinf(theta_m);
+    V3 m(cosf(phi) * st, sinf(phi) * st, cosf(theta_m));
+    V3 T, B;
+    onb(N, T, B);
+    return T * m.x + B * m.y + N * m.z;
+}
+RT_DEV float microfacet_pdf(const V3& V, const V3& H, const V3& N, float alpha, bool beckmann) { // Material.cpp:31-34
+    float D = beckmann ? beckmann_D(N, H, alpha) : ggx_D(N, H, alpha);
+    return D * fmax_sel(dot(H, N), 0.f) / (4.f * fmax_sel(dot(V, H), 0.f) + 0.0000001f);
+}
+RT_DEV V3 fresnel_schlick(float vdh, const V3& F0) { // Material.cpp:37-40
+    float p = pow5(clampf(1.f - vdh, 0.f, 1.f));
+    return F0 + (V3(1.f) - F0) * p;
+}
+RT_DEV float schlick_ggx_G1(float ndv, float rough) { // Material.cpp:42-48
+    float k = rough * rough * 0.5f;
+    float denom = ndv * (1.f - k) + k;
+    if (denom == 0.f) return 0.f;
+    return ndv / denom;
+}
+RT_DEV V3 microfacet_eval(const V3& n, const V3& V, const V3& H, const V3& L, float rough, bool beckmann) { // Material.cpp:57-66
+    float alpha = rough * rough;
+    float D = beckmann ? beckmann_D(n, H, alpha) : ggx_D(n, H, alpha);
+    V3 F = fresnel_schlick(fmax_sel(dot(V, H), 0.f), V3(0.8f));
+    float G = schlick_ggx_G1(fmax_sel(dot(n, V), 0.f), rough) * schlick_ggx_G1(fmax_sel(dot(n, L), 0.f), rough);
+    float denom = 4.0f * fmax_sel(dot(n, V), 0.f) * fmax_sel(dot(n, L), 0.f) + 0.0000001f;
+    return (fmax_sel(dot(n, L), 0.f) * ((D * F) * G)) / denom;
+}
+
+// ---- Disney lobes (Material.cpp:114-722)
+RT_DEV float diffuse_fresnel(float ndw, float f90) { return 1.f + (f90 - 1.f) * pow5(1.f - ndw); }
+
+RT_DEV V3 disney_diffuse_core(const V3& albedo, float rough, float subsurface, float hdo, float ndo, float ndi) {
+    float fd90 = 0.5f + 2.f * rough * hdo * hdo;
+    V3 base = ((albedo / kPi) * diffuse_fresnel(ndi, fd90)) * diffuse_fresnel(ndo, fd90) * ndo;
+    float fss90 = rough * hdo * hdo;
+    float ss = diffuse_fresnel(ndi, fss90) * diffuse_fresnel(ndo, fss90) * (1.f / (ndi + ndo) - 0.5f) + 0.5f;
+    V3 sub = ((1.25f * albedo) / kPi) * ss * ndo;
+    return (1.f - subsurface) * base + subsurface * sub;
+}
+RT_DEV float tr_D(const V3& H, float ax, float ay) { // Material.cpp:160-164
+    float hx = H.x / ax, hy = H.y / ay;
+    float inner = hx * hx + hy * hy + H.z * H.z;
+    float denom = (kPi * ax * ay) * (inner * inner);
+    return 1.f / denom;
+}
+RT_DEV float smith_G1(const V3& w, float ax, float ay) { // Material.cpp:166-171
+    float inner = 1.f + (w.x * ax * w.x * ax + w.y * ay * w.y * ay) / (w.z * w.z);
+    float denom = 1.f + (sqrtf(1.f + inner) - 1.f) / 2.f;
+    return 1.f / denom;
+}
+RT_DEV V3 sample_vndf(const V3& Wi, float ax, float ay, Rng& r) { // Material.cpp:178-199
+    float r1 = r.next();
+    float r2 = r.next();
+    V3 Vh = normalize(V3(ax * Wi.x, ay * Wi.y, Wi.z));
+    float l2 = Wi.x * Wi.x + Wi.y * Wi.y;
+    V3 T1 = l2 > 0.f ? V3(-Vh.y, Vh.x, 0.f) / sqrtf(l2) : V3(1.f, 0.f, 0.f);
+    V3 T2 = cross(T1, Vh);
+    float rr = sqrtf(r1);
+    float phi = 2.0f * kPi * r2;
+    float t1 = rr * cosf(phi);
+    float t2 = rr * sinf(phi);
+    float s = 0.5f * (1.f + Vh.z);
+    t2 = (1.f - s) * sqrtf(1.f - t1 * t1) + s * t2;
+    V3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmax_sel(1.f - t1 * t1 - t2 * t2, 0.f)) * Vh;
+    return normalize(V3(ax * Nh.x, ay * Nh.y, fmax_sel(0.f, Nh.z)));
+}
+RT_DEV void aniso_alphas(float rough, float aniso, float& ax, float& ay) { // Material.cpp:216-218
+    float aspect = sqrtf(1.0f - aniso * 0.9f);
+    ax = fmax_sel(0.001f, rough * rough / aspect);
+    ay = fmax_sel(0.001f, rough * rough * aspect);
+}
+RT_DEV V3 disney_metal_eval(const V3& V, const V3& L, const V3& H, float ax, float ay, const V3& base, float* pdf) { // Material.cpp:201-212
+    V3 F = fresnel_schlick(fmax_sel(dot(V, H), 0.f), base);
+    float D = tr_D(H, ax, ay);
+    float g1 = smith_G1(V, ax, ay);
+    float g2 = smith_G1(L, ax, ay);
+    float G = g1 * g2;
+    *pdf = D * g1 / (4.f * V.z);
+    return ((F * D) * G) / (4.f * V.z);
+}
+RT_DEV float r0_from_ior(float ior) { return ((ior - 1.f) * (ior - 1.f)) / ((ior + 1.f) * (ior + 1.f)); } // Material.cpp:256-259
+RT_DEV float clearcoat_D(float ag, float hdn) {                                                            // Material.cpp:260-265
+    float ag2 = ag * ag;
+    float denom = kPi * logf(ag2) * (1.f + (ag2 - 1.f) * hdn * hdn);
+    return (ag2 - 1.f) / denom;
+}
+RT_DEV V3 clearcoat_sample(float ag, Rng& r) { // Material.cpp:267-280
+    float ag2 = ag * ag;
+    float r1 = r.next();
+    float r2 = r.next();
+    float phi = 2.f * kPi * r2;
+    float ct = sqrtf((1.f - powf(ag2, 1.f - r1)) / (1.f - ag2));
+    float st = clampf(sqrtf(1.f - (ct * ct)), 0.f, 1.f);
+    return V3(st * cosf(phi), st * sinf(phi), ct);
+}
+RT_DEV V3 clearcoat_eval(const V3& V, const V3& L, const V3& H, float gloss, float* pdf) { // Material.cpp:282-294
+    float r0 = r0_from_ior(1.5f);
+    float ag = (1.f - gloss) * 0.1f + gloss * 0.001f;
+    float Fs = r0 + (1.f - r0) * pow5(1.f - fmax_sel(dot(H, L), 0.f));
+    float D = clearcoat_D(ag, H.z);
+    float G = smith_G1(V, 0.25f, 0.25f) * smith_G1(L, 0.25f, 0.25f);
+    *pdf = D / (4.f * fmax_sel(dot(H, L), 0.f) + 0.00000001f);
+    return ((V3(Fs) * D) * G) / (4.f * V.z);
+}
+RT_DEV float dielectric_fresnel3(float ndi, float ndt, float eta) { // Material.cpp:343-349
+    float rs = (ndi - eta * ndt) / (ndi + eta * ndt);
+    float rp = (ndi * eta - ndt) / (ndi * eta + ndt);
+    return (rs * rs + rp * rp) / 2.f;
+}
+RT_DEV float dielectric_fresnel(float ndi, float eta) { // Material.cpp:350-357
+    float ndt2 = 1.f - (1.f - ndi * ndi) / (eta * eta);
+    if (ndt2 < 0.f) return 1.f;
+    return dielectric_fresnel3(fabsf(ndi), sqrtf(ndt2), eta);
+}
+RT_DEV V3 disney_refraction_eval(const V3& V, const V3& L, const V3& H, float eta, float ax, float ay, const V3& base, float* pdf) { // Material.cpp:360-377
+    float D = tr_D(H, ax, ay);
+    float hdi = dot(H, V);
+    float F = dielectric_fresnel(hdi, 1.f / eta);
+    float g1 = smith_G1(V, ax, ay);
+    float g2 = smith_G1(L, ax, ay);
+    float G = g1 * g2;
+    float hdo = fabsf(dot(H, L));
+    float sd = hdi + eta * hdo;
+    V3 out = (((((base * (1.f - F)) * D) * G) * eta) * eta) * fabsf(hdo * hdi) / (fabsf(V.z) * sd * sd);
+    float dh = eta * eta * hdo / (sd * sd);
+    *pdf = (1.f - F) * D * g1 * fabsf(dh * hdi / V.z);
+    return out;
+}
+RT_DEV V3 disney_reflection_eval(const V3& V, const V3& L, const V3& H, float eta, float ax, float ay, const V3& base, float* pdf) { // Material.cpp:379-392
+    float hdi = dot(H, V);
+    float F = dielectric_fresnel(hdi, eta);
+    float D = tr_D(H, ax, ay);
+    float g1 = smith_G1(V, ax, ay);
+    float g2 = smith_G1(L, ax, ay);
+    float G = g1 * g2;
+    *pdf = F * D * g1 / (4.f * V.z);
+    return (((base * F) * D) * G) / (4.f * V.z);
+}
+
+struct UberP { // DisneyUber fields, Material.h:183-196
+    V3 base;
+    float spec_trans, metallic, subsurface, specular, rough, spec_tint, aniso, clearcoat, ior;
+};
+RT_DEV UberP uber_params(const rt_material& m) {
+    UberP u;
+    u.base = V3(m.c0);
+    u.spec_trans = m.s[0]; u.metallic = m.s[1]; u.subsurface = m.s[2]; u.specular = m.s[3]; u.rough = m.s[4];
+    u.spec_tint = m.s[5]; u.aniso = m.s[6]; u.clearcoat = m.s[9]; u.ior = m.s[11];
+    return u;
+}
+RT_DEV V3 uber_diffuse(const UberP& u, const V3& V, const V3& L, const V3& H, float* pdf) { // Material.cpp:571-589
+    *pdf = fmax_sel(L.z, 0.f) / kPi;
+    V3 d = disney_diffuse_core(u.base, u.rough, u.subsurface, fmax_sel(dot(H, L), 0.f), fmax_sel(L.z, 0.f), fmax_sel(V.z, 0.f));
+    return (d * (1.f - u.spec_trans)) * (1.f - u.metallic);
+}
+RT_DEV V3 uber_metal(const UberP& u, const V3& V, const V3& L, const V3& H, float eta, float ax, float ay, float* pdf) { // Material.cpp:591-609
+    V3 c_tint = u.base / luminance(u.base);
+    V3 ks = V3(1.f - u.spec_tint) + u.spec_tint * c_tint;
+    V3 C0 = ((u.specular * r0_from_ior(eta)) * (1.f - u.metallic)) * ks + u.metallic * u.base;
+    float p = pow5(1.f - fmax_sel(dot(L, H), 0.f));
+    V3 F = C0 + (V3(1.f) - C0) * p;
+    float D = tr_D(H, ax, ay);
+    float g1 = smith_G1(V, ax, ay);
+    float g2 = smith_G1(L, ax, ay);
+    float G = g1 * g2;
+    *pdf = D * g1 / (4.f * V.z);
+    V3 f = ((F * D) * G) / (4.f * V.z);
+    return f * (1.f - u.spec_trans * (1.f - u.metallic));
+}
+
+RT_DEV V3 mat_emitted(const rt_material& m) { return m.type == RT_MAT_EMISSIVE ? V3(m.c0) : V3(0.f); }
+
+// Material::Eval
+RT_DEV V3 mat_eval(const rt_material& m, const Surf& si, const V3& in_dir, const V3& out_dir, float* pdf) {
+    const V3 n = si.normal;
+    switch (m.type) {
+    case RT_MAT_MATTE: { // Material.h:81-88
+        float c = fmax_sel(dot(n, out_dir), 0.f);
+        *pdf = c / kPi;
+        return (V3(m.c0) * c) / kPi;
+    }
+    case RT_MAT_MICROFACET_GGX:
+    case RT_MAT_MICROFACET_BECKMANN: { // Material.cpp:87-98
+        const bool beck = m.type == RT_MAT_MICROFACET_BECKMANN;
+        V3 Wo = -in_dir;
+        V3 Wh = normalize(Wo + out_dir);
+        *pdf = microfacet_pdf(Wo, Wh, n, m.s[0] * m.s[0], beck);
+        return microfacet_eval(n, Wo, Wh, out_dir, m.s[0], beck);
+    }
+    case RT_MAT_DISNEY_DIFFUSE: { // Material.cpp:128-153
+        *pdf = fmax_sel(dot(n, out_dir), 0.f) / kPi;
+        V3 Wh = normalize(-in_dir + out_dir);
+        return disney_diffuse_core(V3(m.c0), m.s[0], m.s[1], fmax_sel(dot(Wh, out_dir), 0.f), fmax_sel(dot(n, out_dir), 0.f),
+                                   fmax_sel(dot(n, -in_dir), 0.f));
+    }
+    case RT_MAT_DISNEY_SHEEN: { // Material.cpp:554-567
+        *pdf = fmax_sel(dot(n, out_dir), 0.f) / kPi;
+        V3 half = normalize(-in_dir + out_dir);
+        V3 base(m.c0);
+        float denom = luminance(base);
+        if (denom < 0.f) denom = 1.f;
+        V3 tint = base / denom;
+        V3 c = V3(1.f - m.s[0]) + m.s[0] * tint;
+        return (c * pow5(1.f - fabsf(dot(half, out_dir)))) * dot(n, out_dir);
+    }
+    case RT_MAT_EMISSIVE:
+    case RT_MAT_GLASS:
+        *pdf = 0.f;
+        return V3(0.f);
+    default: break;
+    }
+    // tangent-space lobes
+    V3 T, B;
+    onb(n, T, B);
+    const V3 V(dot(-in_dir, T), dot(-in_dir, B), dot(-in_dir, n));
+    const V3 L(dot(out_dir, T), dot(out_dir, B), dot(out_dir, n));
+    switch (m.type) {
+    case RT_MAT_DISNEY_METAL: { // Material.cpp:234-248
+        float ax, ay;
+        aniso_alphas(m.s[0], m.s[1], ax, ay);
+        return disney_metal_eval(V, L, normalize(V + L), ax, ay, V3(m.c0), pdf);
+    }
+    case RT_MAT_DISNEY_CLEARCOAT: // Material.cpp:314-325
+        return clearcoat_eval(V, L, normalize(V + L), m.s[0], pdf);
+    case RT_MAT_DISNEY_GLASS: { // Material.cpp:432-456
+        const bool refl = dot(n, out_dir) >= 0.f;
+        const float eta = si.front_face ? 1.f / m.s[2] : m.s[2];
+        float ax, ay;
+        aniso_alphas(m.s[0], m.s[1], ax, ay);
+        if (refl) return disney_reflection_eval(V, L, normalize(V + L), eta, ax, ay, V3(m.c0), pdf);
+        return disney_refraction_eval(V, L, normalize(V + L * eta), eta, ax, ay, V3(m.c0), pdf);
+    }
+    case RT_MAT_ROUGH_DIELECTRIC: { // Material.cpp:494-541
+        const bool refl = dot(n, out_dir) <= 0.f; // as written in the reference
+        const float eta = si.front_face ? 1.f / m.s[0] : m.s[0];
+        V3 hv = refl ? normalize(-in_dir + out_dir) : normalize(-in_dir + out_dir * eta);
+        const V3 lh(dot(hv, T), dot(hv, B), dot(hv, n));
+        if (hv.z < 0.f) hv = -hv; // dot(half_vec, vec3(0,0,1)) < 0
+        const float hdi = dot(hv, -in_dir);
+        const float F = dielectric_fresnel(hdi, eta);
+        const float alpha = m.s[1] * m.s[1];
+        const float D = tr_D(lh, alpha, alpha);
+        const float g1 = smith_G1(V, alpha, alpha);
+        const float g2 = smith_G1(L, alpha, alpha);
+        const float G = g1 * g2;
+        if (refl) {
+            *pdf = (F * D * g1) / (4.f * fabsf(V.z));
+            return (V3(m.c0) * (F * D * G)) / (4.f * fabsf(V.z));
+        }
+        const float hdo = fabsf(dot(hv, out_dir));
+        const float sd = hdi + eta * hdo;
+        V3 out = (((((V3(m.c1) * (1.f - F)) * D) * G) * eta) * eta) * fabsf(hdo * hdi) / (fabsf(V.z) * sd * sd);
+        const float dh = eta * eta * hdo / (sd * sd);
+        *pdf = (1.f - F) * D * g1 * fabsf(dh * hdi / V.z);
+        return out;
+    }
+    case RT_MAT_DISNEY_UBER: { // Material.cpp:678-722
+        const UberP u = uber_params(m);
+        const V3 H = normalize(V + L);
+        float dw = (1.f - u.metallic) * (1.f - u.spec_trans);
+        float mw = (1.f - u.spec_trans * (1.f - u.metallic));
+        float gw = (1.f - u.metallic) * u.spec_trans;
+        float cw = 0.25f * u.clearcoat;
+        if (!si.front_face) dw = mw = cw = 0.f;
+        const float sum = dw + mw + gw + cw;
+        dw /= sum;
+        mw /= sum;
+        float ax, ay;
+        aniso_alphas(u.rough, u.aniso, ax, ay);
+        const float eta = si.front_face ? 1.f / u.ior : u.ior;
+        float p, total = 0.f;
+        V3 f(0.f);
+        if (dw > 0.f) {
+            f = f + uber_diffuse(u, V, L, H, &p);
+            total += p * dw;
+        }
+        if (mw > 0.f) {
+            f = f + uber_metal(u, V, L, H, eta, ax, ay, &p);
+            total += p * mw;
+        }
+        *pdf = total;
+        return f;
+    }
+    default:
+        *pdf = 0.f;
+        return V3(0.f);
+    }
+}
+
+// Material::Sample_Eval
+RT_DEV Scatter mat_sample(const rt_material& m, const Surf& si, const V3& in_dir, Rng& r) {
+    Scatter sc;
+    sc.origin = V3(0.f);
+    sc.dir = V3(1.f, 0.f, 0.f); // Ray(), Math.h:624
+    sc.f = V3(0.f);
+    sc.pdf = 0.f;
+    const V3 n = si.normal;
+    switch (m.type) {
+    case RT_MAT_MATTE:          // Material.h:71-79
+    case RT_MAT_DISNEY_DIFFUSE: // Material.cpp:119-127
+    case RT_MAT_DISNEY_SHEEN: { // Material.cpp:545-553
+        V3 d = cosine_sample(r);
+        V3 T, B;
+        onb(n, T, B);
+        d = d.x * T + d.y * B + d.z * n;
+        sc.origin = si.point + n * 0.001f;
+        sc.dir = d;
+        sc.f = mat_eval(m, si, in_dir, d, &sc.pdf);
+        return sc;
+    }
+    case RT_MAT_MICROFACET_GGX:
+    case RT_MAT_MICROFACET_BECKMANN: { // Material.cpp:68-86
+        const bool beck = m.type == RT_MAT_MICROFACET_BECKMANN;
+        const float alpha = m.s[0] * m.s[0];
+        V3 Wo = -in_dir;
+        V3 Wh = microfacet_sample_h(n, alpha, beck, r);
+        V3 Wi = -reflect(-in_dir, Wh);
+        sc.origin = si.point + n * 0.0001f;
+        sc.dir = Wi;
+        sc.pdf = microfacet_pdf(Wo, Wh, n, alpha, beck);
+        if (sc.pdf != sc.pdf) sc.pdf = 0.f;
+        sc.f = microfacet_eval(n, Wo, Wh, Wi, m.s[0], beck);
+        return sc;
+    }
+    case RT_MAT_GLASS: { // Material.h:248-266
+        const float ratio = si.front_face ? (1.0f / m.s[0]) : m.s[0];
+        const float ct = fmin_sel(dot(-in_dir, n), 1.0f);
+        const float st = sqrtf(1.f - ct * ct);
+        bool refl = ratio * st > 1.f;
+        if (!refl) refl = schlick_reflectance(ct, ratio) > r.next(); // the draw is skipped on total internal reflection
+        V3 d = refl ? reflect(in_dir, n) : refract(in_dir, n, ratio);
+        sc.origin = si.point + n * (refl ? 0.001f : -0.001f);
+        sc.dir = normalize(d);
+        sc.pdf = 1.f;
+        sc.f = V3(1.f);
+        return sc;
+    }
+    case RT_MAT_EMISSIVE: return sc; // Material.h:56-59
+    default: break;
+    }
+    V3 T, B;
+    onb(n, T, B);
+    const V3 V(dot(-in_dir, T), dot(-in_dir, B), dot(-in_dir, n));
+    switch (m.type) {
+    case RT_MAT_DISNEY_METAL: { // Material.cpp:214-233
+        float ax, ay;
+        aniso_alphas(m.s[0], m.s[1], ax, ay);
+        V3 H = sample_vndf(V, ax, ay, r);
+        V3 L = reflect(-V, H);
+        sc.f = disney_metal_eval(V, L, H, ax, ay, V3(m.c0), &sc.pdf);
+        sc.dir = L.x * T + L.y * B + L.z * n;
+        sc.origin = si.point + n * 0.00001f;
+        return sc;
+    }
+    case RT_MAT_DISNEY_CLEARCOAT: { // Material.cpp:297-313
+        float ag = (1.f - m.s[0]) * 0.1f + m.s[0] * 0.001f;
+        V3 H = clearcoat_sample(ag, r);
+        V3 L = reflect(-V, H);
+        sc.f = clearcoat_eval(V, L, H, m.s[0], &sc.pdf);
+        sc.dir = L.x * T + L.y * B + L.z * n;
+        sc.origin = si.point + n * 0.00001f;
+        return sc;
+    }
+    case RT_MAT_DISNEY_GLASS: { // Material.cpp:396-431
+        const float eta = si.front_face ? (1.f / m.s[2]) : m.s[2];
+        float ax, ay;
+        aniso_alphas(m.s[0], m.s[1], ax, ay);
+        V3 H = sample_vndf(V, ax, ay, r);
+        const float F = dielectric_fresnel(dot(H, V), 1.f / eta);
+        const bool do_reflect = F > r.next();
+        if (do_reflect) {
+            V3 L = normalize(reflect(-V, H));
+            sc.dir = L.x * T + L.y * B + L.z * n;
+            sc.origin = si.point + n * 0.00001f;
+            sc.f = disney_reflection_eval(V, L, H, eta, ax, ay, V3(m.c0), &sc.pdf);
+        } else {
+            V3 L = normalize(refract(-V, H, eta));
+            sc.dir = L.x * T + L.y * B + L.z * n;
+            sc.origin = si.point - n * 0.00001f;
+            sc.f = disney_refraction_eval(V, L, H, eta, ax, ay, V3(m.c0), &sc.pdf);
+        }
+        return sc;
+    }
+    case RT_MAT_ROUGH_DIELECTRIC: { // Material.cpp:463-493
+        const float eta = si.front_face ? 1.f / m.s[0] : m.s[0];
+        const float alpha = m.s[1] * m.s[1];
+        V3 lm = sample_vndf(V, alpha, alpha, r);
+        V3 wh = lm.x * T + lm.y * B + lm.z * n;
+        const float F = dielectric_fresnel(dot(wh, -in_dir), eta);
+        const float r1 = r.next();
+        if (r1 <= F) {
+            sc.dir = normalize(reflect(in_dir, wh));
+            sc.origin = si.point + n * 0.00001f;
+        } else {
+            sc.dir = normalize(refract(in_dir, wh, eta));
+            sc.origin = si.point + n * -0.00001f;
+        }
+        sc.f = mat_eval(m, si, in_dir, sc.dir, &sc.pdf);
+        return sc;
+    }
+    case RT_MAT_DISNEY_UBER: { // Material.cpp:611-677
+        const UberP u = uber_params(m);
+        float dw = (1.f - u.metallic) * (1.f - u.spec_trans);
+        float mw = (1.f - u.spec_trans * (1.f - u.metallic));
+        float gw = (1.f - u.metallic) * u.spec_trans;
+        float cw = 0.25f * u.clearcoat;
+        if (!si.front_face) dw = mw = cw = 0.f;
+        const float c0 = dw, c1 = c0 + mw, c2 = c1 + gw, c3 = c2 + cw;
+        const float sum = c3;
+        const float lobe = r.next() * sum;
+        float ax, ay;
+        aniso_alphas(u.rough, u.aniso, ax, ay);
+        const float eta = si.front_face ? 1.f / u.ior : u.ior;
+        if (lobe < c0) {
+            V3 L = cosine_sample(r);
+            sc.dir = L.x * T + L.y * B + L.z * n;
+            sc.origin = si.point + n * 0.001f;
+            sc.f = uber_diffuse(u, V, L, normalize(V + L), &sc.pdf);
+            sc.pdf = sc.pdf * (dw / sum);
+        } else if (lobe < c1) {
+            V3 H = sample_vndf(V, ax, ay, r);
+            V3 L = reflect(-V, H);
+            sc.dir = L.x * T + L.y * B + L.z * n;
+            sc.origin = si.point + n * 0.001f;
+            sc.f = uber_metal(u, V, L, H, eta, ax, ay, &sc.pdf);
+            sc.pdf *= (mw / sum);
+        } // glass / clearcoat lobes are unwritten in the reference: f = 0, pdf = 0 (Material.cpp:665-673)
+        return sc;
+    }
+    default: return sc;
+    }
+}
+
+// ------------------------------------------------------ environment light
+RT_DEV int imod(int a, int b) { // Math.h:44-47
+    int r = a % b;
+    return (r < 0) ? r + b : r;
+}
+RT_DEV V3 env_texel(const SceneView& sc, int x, int y) { return V3(sc.env_rgb + ((size_t)sc.env_w * y + x) * 3); }
+RT_DEV V3 env_lookup(const SceneView& sc, float u, float v) { // Image.h:46-64
+    const int w = sc.env_w, h = sc.env_h;
+    u = u * w - 0.5f;
+    v = v * h - 0.5f;
+    int ufi = imod((int)u, w);
+    int vfi = imod((int)v, h);
+    int uci = imod(ufi + 1, w);
+    int vci = imod(vfi + 1, h);
+    float ip;
+    float uo = modff(u - ufi, &ip);
+    float vo = modff(v - vfi, &ip);
+    V3 ff = env_texel(sc, ufi, vfi), fc = env_texel(sc, ufi, vci), cf = env_texel(sc, uci, vfi), cc = env_texel(sc, uci, vci);
+    return (ff * (1.f - uo)) * (1.f - vo) + (fc * (1.f - uo)) * (vo) + (cf * (uo)) * (1.f - vo) + (cc * (uo)) * (vo);
+}
+RT_DEV float env_pdf_of(const SceneView& sc, const V3& color, float theta) {
+    float pdf = luminance(color) / sc.env_total;
+    float st = sinf(theta);
+    if (st == 0.f) return 0.f;
+    return pdf * ((float)(sc.env_w * sc.env_h) / (2.f * kPi * kPi * st));
+}
+RT_DEV V3 env_eval(const SceneView& sc, const V3& dir, float* pdf) { // main.cpp:144-164
+    float theta = acosf(dir.y);
+    float phi = atan2f(dir.z, dir.x);
+    float u = (kPi + phi) / kPi * 0.5f + sc.env_offset;
+    float v = theta / kPi;
+    V3 color = env_lookup(sc, u, v);
+    *pdf = env_pdf_of(sc, color, theta);
+    return color;
+}
+RT_DEV V3 env_sample(const SceneView& sc, float rnd, V3* dir, float* pdf) { // main.cpp:121-143,165-184
+    const int w = sc.env_w, h = sc.env_h;
+    int lo = 0, hi = h - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (rnd < sc.env_cdf[(mid + 1) * w - 1]) hi = mid;
+        else lo = mid + 1;
+    }
+    const int y = lo;
+    lo = 0;
+    hi = w - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (rnd < sc.env_cdf[y * w + mid]) hi = mid;
+        else lo = mid + 1;
+    }
+    const int x = lo;
+    float ux = (float)x / w, uy = (float)y / h;
+    V3 color = env_lookup(sc, ux, uy);
+    ux -= sc.env_offset;
+    float phi = ux * 2.f * kPi;
+    float theta = uy * kPi;
+    float st = sinf(theta);
+    *dir = V3(-st * cosf(phi), cosf(theta), -st * sinf(phi));
+    *pdf = env_pdf_of(sc, color, theta);
+    return color;
+}
+
+// Instance::sample_geometry (Object.h:396-403) for a RECT light, area-CDF
+// triangle pick for a TRIMESH light (extension).
+RT_DEV void light_sample(const SceneView& sc, const rt_light& L, Rng& r, V3* point, V3* normal) {
+    if (L.kind == RT_LIGHT_RECT) {
+        float r1 = -1.f + 2.f * r.next(); // random_float(-1,1), Utils.h:12-15
+        float r2 = -1.f + 2.f * r.next();
+        V3 p = (V3(L.t) * L.hu) * r1 + (V3(L.b) * L.hv) * r2;
+        const float* m = L.m;
+        *point = V3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.f, m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.f,
+                    m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.f);
+        const float* im = L.inv_m;
+        const V3 N(L.n);
+        *normal = V3(im[0] * N.x + im[1] * N.y + im[2] * N.z, im[4] * N.x + im[5] * N.y + im[6] * N.z,
+                     im[8] * N.x + im[9] * N.y + im[10] * N.z);
+        return;
+    }
+    float r0 = r.next();
+    float b1 = r.next();
+    float b2 = r.next();
+    int lo = 0, hi = L.count - 1;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (r0 < sc.emissive[L.first + mid].cdf) hi = mid;
+        else lo = mid + 1;
+    }
+    const int slot = sc.emissive[L.first + lo].slot;
+    const float4* tp = sc.tris + 3 * (size_t)slot;
+    const float4* np = sc.normals + 3 * (size_t)slot;
+    float su = sqrtf(b1);
+    float u = 1.f - su;
+    float v = b2 * su;
+    *point = V3(tp[0]) + u * V3(tp[1]) + v * V3(tp[2]);
+    V3 N = (1.f - u - v) * V3(np[0]) + u * V3(np[1]) + v * V3(np[2]);
+    *normal = normalize(N);
+}
+
+// hammersley_2d + Camera::get_ray + Filter::sample (Utils.h:138-151, Scene.h:61-75, Filter.h)
+RT_DEV void camera_ray(const rt_camera& cam, int x, int y, uint32_t i, uint32_t n, V3* o, V3* d) {
+    float hx = (float)i / (float)n;
+    float hy = (float)__brev(i) * 2.3283064365386963e-10f;
+    float rx = hx + (float)x;
+    float ry = hy + (float)y;
+    float fx = floorf(rx), fy = floorf(ry);
+    float dx = rx - fx;
+    float dy = ry - fy;
+    float ox, oy;
+    if (cam.filter == RT_FILTER_GAUSSIAN) {
+        float rad = cam.filter_param * sqrtf(-2.f * logf(fmax_sel(dx, 1e-8f)));
+        ox = rad * cosf(2.f * kPi * dy);
+        oy = rad * sinf(2.f * kPi * dy);
+    } else {
+        ox = (2.f * dx - 1.f) * (cam.filter_param * 0.5f);
+        oy = (2.f * dy - 1.f) * (cam.filter_param * 0.5f);
+    }
+    float px = (fx + 0.5f) + ox;
+    float py = (fy + 0.5f) + oy;
+    const float* m = cam.raster_to_world;
+    V3 pos(m[0] * px + m[4] * py + m[8] * 0.f + m[12] * 1.f, m[1] * px + m[5] * py + m[9] * 0.f + m[13] * 1.f,
+           m[2] * px + m[6] * py + m[10] * 0.f + m[14] * 1.f);
+    *o = V3(cam.pos);
+    *d = normalize(pos - *o);
+}
+
+} // namespace rtd

@@ -1,0 +1,530 @@
+// Scene.cpp — host scene: mesh BVH build, light tables, flattening into the
+// GPU layout of include/rt_hip.h, upload, and the query/render forwards.
+#include "Scene.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+namespace rt {
+
+// ------------------------------------------------------------------ Mesh
+Bounds tri_bounds(const vec3& v1, const vec3& v2, const vec3& v3) { // Object.cpp:3-9
+    Bounds b(v1);
+    b = bounds_union(b, v2);
+    b = bounds_union(b, v3);
+    return b;
+}
+
+void Mesh::build() { build(1, BVH_SAH); } // Object.cpp:21
+
+void Mesh::build(int max_per_leaf, PartitionStrategy strat) {
+    std::vector<Bounds> b;
+    b.reserve(triangles.size());
+    for (const MeshTriangle& t : triangles)
+        b.push_back(tri_bounds(verts[t.indicies[0]].position, verts[t.indicies[1]].position, verts[t.indicies[2]].position));
+    accelStructure = BVH::build(b, max_per_leaf, strat);
+}
+
+// --------------------------------------------------------- Filter / Camera
+vec2 BoxFilter::sample(float dx, float dy) const { // Filter.h:18-23
+    vec2 s(2 * dx - 1, 2 * dy - 1);
+    s.x *= width * 0.5;
+    s.y *= width * 0.5;
+    return s;
+}
+vec2 GaussianFilter::sample(float dx, float dy) const { // Filter.h:34-38
+    float r = stddev * std::sqrt(-2 * std::log((double)fmax_sel(dx, 1e-8)));
+    return vec2(r * std::cos((double)(2 * PI * dy)), r * std::sin((double)(2 * PI * dy)));
+}
+
+Camera::Camera(const mat4& view_matrix, float fov, int width, int height, Filter* f) { // Scene.h:14-44
+    mat4 raster_to_screen;
+    raster_to_screen.m[0] = 2.f / width;
+    raster_to_screen.m[5] = 2.f / height;
+    raster_to_screen.m[10] = 1;
+    raster_to_screen.m[12] = -1;
+    raster_to_screen.m[13] = -1;
+    raster_to_screen.m[14] = 1;
+    raster_to_screen.m[15] = 1;
+    float h = std::tan((double)radians(fov / 2.f));
+    float aspect = (float)width / height;
+    mat4 screen_to_camera;
+    screen_to_camera.m[0] = h * aspect;
+    screen_to_camera.m[5] = h;
+    screen_to_camera.m[10] = -1;
+    screen_to_camera.m[15] = 1;
+    raster_to_world = view_matrix * screen_to_camera * raster_to_screen;
+    camera_pos = view_matrix.column(3).xyz();
+    filter = f ? f : new GaussianFilter(0.5);
+}
+
+Camera& Camera::operator=(Camera&& other) { // Scene.h:49-58
+    delete filter;
+    filter = other.filter;
+    camera_pos = other.camera_pos;
+    raster_to_world = other.raster_to_world;
+    other.filter = nullptr;
+    return *this;
+}
+
+Ray Camera::get_ray(float raster_x, float raster_y) const { // Scene.h:61-75
+    float dx = raster_x - std::floor(raster_x);
+    float dy = raster_y - std::floor(raster_y);
+    vec2 offset = filter->sample(dx, dy);
+    float px = (std::floor(raster_x) + 0.5f) + offset.x;
+    float py = (std::floor(raster_y) + 0.5f) + offset.y;
+    vec3 pos = (raster_to_world * vec4(px, py, 0, 1)).xyz();
+    return Ray(camera_pos, normalize(pos - camera_pos));
+}
+
+rt_camera Camera::flatten() const {
+    rt_camera c{};
+    std::memcpy(c.raster_to_world, raster_to_world.m, sizeof(c.raster_to_world));
+    c.pos[0] = camera_pos.x;
+    c.pos[1] = camera_pos.y;
+    c.pos[2] = camera_pos.z;
+    c.filter = RT_FILTER_GAUSSIAN;
+    c.filter_param = 0.5f;
+    if (filter) filter->describe(&c.filter, &c.filter_param);
+    return c;
+}
+
+// ------------------------------------------------------------------ Image
+vec3 Image::get(int x, int y) const { // Image.h:19-43
+    switch (internalFormat) {
+    case Format::RGBA_32f: {
+        const float* d = (const float*)imageData.data() + ((size_t)width * y + x) * 4;
+        return vec3(d[0], d[1], d[2]);
+    }
+    case Format::RGB_32f: {
+        const float* d = (const float*)imageData.data() + ((size_t)width * y + x) * 3;
+        return vec3(d[0], d[1], d[2]);
+    }
+    case Format::RGBA_u8: {
+        const uint8_t* d = (const uint8_t*)imageData.data() + ((size_t)width * y + x) * 4;
+        return vec3(d[0], d[1], d[2]) / 255.f;
+    }
+    case Format::RGB_u8: {
+        const uint8_t* d = (const uint8_t*)imageData.data() + ((size_t)width * y + x) * 3;
+        return vec3(d[0], d[1], d[2]) / 255.f;
+    }
+    default: return vec3(0);
+    }
+}
+
+HDRImage* make_uniform_environment(int width, int height, vec3 radiance) {
+    HDRImage* img = new HDRImage;
+    img->width = width;
+    img->height = height;
+    img->internalFormat = Image::Format::RGB_32f;
+    img->imageData.resize((size_t)width * height * 3 * sizeof(float));
+    float* d = (float*)img->imageData.data();
+    for (int i = 0; i < width * height; i++) {
+        d[3 * i] = radiance.x;
+        d[3 * i + 1] = radiance.y;
+        d[3 * i + 2] = radiance.z;
+    }
+    return img;
+}
+
+// -------------------------------------------------------------- Rectangle
+Rectangle::Rectangle(vec3 normal, vec3 tangent, float u_length, float v_length) { // Object.h:64-70
+    N = normal;
+    T = tangent;
+    B = normalize(cross(N, T));
+    u = u_length / 2;
+    v = v_length / 2;
+}
+Rectangle::Rectangle(vec3 normal, float u_length, float v_length) { // Object.h:71-80
+    N = normal;
+    vec3 up(0, 1, 0);
+    if (N.y < -0.999) up = vec3(1, 0, 0);
+    else if (N.y > 0.999) up = vec3(0, 0, -1);
+    T = normalize(cross(up, N));
+    B = normalize(cross(N, T));
+    u = u_length / 2;
+    v = v_length / 2;
+}
+
+// ------------------------------------------------------------------ Scene
+Scene::~Scene() {
+    if (gpu_scene) rt_scene_destroy(gpu_scene);
+    for (Material* m : materials) delete m;
+    for (Image* i : images) delete i;
+    for (Instance& l : lights) l.free_data();
+    delete environment;
+}
+
+void Scene::set_environment(HDRImage* img, float degrees_offset) {
+    delete environment;
+    environment = img;
+    environment_offset = degrees_offset / 360.f; // main.cpp:94
+}
+
+void Scene::add_rectangle_light(vec3 normal, float u_length, float v_length, vec3 emit, const mat4& transform) {
+    Rectangle* rect = new Rectangle(normal, u_length, v_length);
+    lights.push_back(Instance(rect, new EmissiveMaterial(emit), transform));
+    const Transform& tf = lights.back().get_transform();
+    const uint32_t mat = (uint32_t)materials.size();
+    materials.push_back(new EmissiveMaterial(emit));
+
+    vec3 n = normalize(tf.to_world_normal(rect->N)); // Object.h:389-390
+    vec3 tu = rect->T * rect->u, bv = rect->B * rect->v;
+    vec3 corner[4] = {-tu - bv, tu - bv, tu + bv, -tu + bv};
+    const uint32_t base = (uint32_t)sceneMergedMesh.verts.size();
+    for (int i = 0; i < 4; i++) {
+        Vertex vtx;
+        vtx.position = tf.to_world_point(corner[i]);
+        vtx.normal = n;
+        vtx.uv = vec2((i == 1 || i == 2) ? 1.f : 0.f, (i >= 2) ? 1.f : 0.f);
+        sceneMergedMesh.verts.push_back(vtx);
+    }
+    light_first_tri.push_back((int)sceneMergedMesh.triangles.size());
+    MeshTriangle a, b;
+    a.indicies[0] = base; a.indicies[1] = base + 1; a.indicies[2] = base + 2;
+    b.indicies[0] = base; b.indicies[1] = base + 2; b.indicies[2] = base + 3;
+    a.materialIndex = b.materialIndex = mat;
+    sceneMergedMesh.triangles.push_back(a);
+    sceneMergedMesh.triangles.push_back(b);
+}
+
+void Scene::build_acceleration(int max_per_leaf, PartitionStrategy strat) { sceneMergedMesh.build(max_per_leaf, strat); }
+
+static void put3(float* d, const vec3& v) {
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+
+void Scene::flatten() {
+    FlatScene& f = flat_scene;
+    f = FlatScene();
+    const Mesh& mesh = sceneMergedMesh;
+    const BVH& bvh = mesh.accelStructure;
+    const size_t n_tris = mesh.triangles.size();
+    if (bvh.nodes.empty()) return;
+
+    // ---- lights: rectangles first (Scene::lights order), then one TRIMESH
+    // light per emissive material that still owns triangles.
+    f.tri_light.assign(n_tris, -1);
+    for (size_t i = 0; i < lights.size(); i++) {
+        const Rectangle* rect = static_cast<const Rectangle*>(lights[i].get_geometry());
+        rt_light L{};
+        L.kind = RT_LIGHT_RECT;
+        L.material = (int32_t)mesh.triangles[light_first_tri[i]].materialIndex;
+        L.area = lights[i].get_area(); // ignores transform scaling, Object.h:404-407
+        put3(L.n, rect->N);
+        put3(L.t, rect->T);
+        put3(L.b, rect->B);
+        L.hu = rect->u;
+        L.hv = rect->v;
+        std::memcpy(L.m, lights[i].get_transform().matrix().m, sizeof(L.m));
+        std::memcpy(L.inv_m, lights[i].get_transform().inverse_matrix().m, sizeof(L.inv_m));
+        f.lights.push_back(L);
+        f.tri_light[light_first_tri[i]] = (int32_t)i;
+        f.tri_light[light_first_tri[i] + 1] = (int32_t)i;
+    }
+    std::map<uint32_t, std::vector<int>> emissive_by_material;
+    for (size_t t = 0; t < n_tris; t++) {
+        if (f.tri_light[t] >= 0) continue;
+        uint32_t m = mesh.triangles[t].materialIndex;
+        if (m >= materials.size()) continue;
+        vec3 e = materials[m]->emitted();
+        if (e.x > 0 || e.y > 0 || e.z > 0) emissive_by_material[m].push_back((int)t);
+    }
+    // slot of every original triangle
+    std::vector<int> slot_of(n_tris, -1);
+    for (size_t k = 0; k < bvh.indicies.size(); k++) slot_of[bvh.indicies[k]] = (int)k;
+    for (auto& kv : emissive_by_material) {
+        rt_light L{};
+        L.kind = RT_LIGHT_TRIMESH;
+        L.material = (int32_t)kv.first;
+        L.first = (int32_t)f.emissive.size();
+        L.count = (int32_t)kv.second.size();
+        std::vector<float> areas;
+        double total = 0;
+        for (int t : kv.second) {
+            const MeshTriangle& T = mesh.triangles[t];
+            vec3 e1 = mesh.verts[T.indicies[1]].position - mesh.verts[T.indicies[0]].position;
+            vec3 e2 = mesh.verts[T.indicies[2]].position - mesh.verts[T.indicies[0]].position;
+            float a = 0.5f * cross(e1, e2).length();
+            areas.push_back(a);
+            total += a;
+        }
+        L.area = (float)total;
+        double run = 0;
+        for (size_t i = 0; i < kv.second.size(); i++) {
+            run += areas[i];
+            rt_emissive_tri et;
+            et.slot = slot_of[kv.second[i]];
+            et.cdf = (i + 1 == kv.second.size()) ? 1.0f : (float)(run / total);
+            f.emissive.push_back(et);
+            f.emissive_orig.push_back(kv.second[i]);
+            f.tri_light[kv.second[i]] = (int32_t)f.lights.size();
+        }
+        f.lights.push_back(L);
+    }
+
+    // ---- triangles in leaf order
+    f.tris.resize(n_tris);
+    f.normals.resize(n_tris);
+    for (size_t k = 0; k < n_tris; k++) {
+        const int t = bvh.indicies[k];
+        const MeshTriangle& T = mesh.triangles[t];
+        const Vertex &a = mesh.verts[T.indicies[0]], &b = mesh.verts[T.indicies[1]], &c = mesh.verts[T.indicies[2]];
+        rt_tri& o = f.tris[k];
+        put3(o.v0, a.position);
+        put3(o.e1, b.position - a.position); // Object.h:247-248
+        put3(o.e2, c.position - a.position);
+        o.tri_id = (uint32_t)t;
+        o.material = (int32_t)T.materialIndex;
+        o.light = f.tri_light[t];
+        rt_tri_normals& nn = f.normals[k];
+        std::memset(&nn, 0, sizeof(nn));
+        put3(nn.n0, a.normal);
+        put3(nn.n1, b.normal);
+        put3(nn.n2, c.normal);
+    }
+
+    // ---- child-pair records, numbered in pre-order of the branch nodes
+    std::vector<int> pair_of(bvh.nodes.size(), -1);
+    {
+        std::vector<int> stack{0};
+        int next = 0;
+        while (!stack.empty()) {
+            int n = stack.back();
+            stack.pop_back();
+            const BVHNode& nd = bvh.nodes[n];
+            if (nd.count != BVH_BRANCH) {
+                f.tris[nd.left_node + nd.count - 1].tri_id |= RT_TRI_LEAF_END;
+                continue;
+            }
+            pair_of[n] = next++;
+            stack.push_back(nd.left_node + 1);
+            stack.push_back(nd.left_node);
+        }
+        f.pairs.resize(next);
+    }
+    auto ref_of = [&](int n) -> int32_t {
+        const BVHNode& nd = bvh.nodes[n];
+        return nd.count == BVH_BRANCH ? pair_of[n] : ~nd.left_node;
+    };
+    f.root_ref = ref_of(0);
+    for (size_t n = 0; n < bvh.nodes.size(); n++) {
+        if (pair_of[n] < 0) continue;
+        const BVHNode& L = bvh.nodes[bvh.nodes[n].left_node];
+        const BVHNode& R = bvh.nodes[bvh.nodes[n].left_node + 1];
+        rt_bvh_pair& p = f.pairs[pair_of[n]];
+        put3(p.lmin, L.aabb.bmin);
+        put3(p.lmax, L.aabb.bmax);
+        put3(p.rmin, R.aabb.bmin);
+        put3(p.rmax, R.aabb.bmax);
+        p.lref = ref_of(bvh.nodes[n].left_node);
+        p.rref = ref_of(bvh.nodes[n].left_node + 1);
+        p.reserved[0] = p.reserved[1] = 0;
+    }
+
+    // ---- materials
+    for (const Material* m : materials) f.materials.push_back(m->flatten());
+
+    // ---- environment CDF: EnviormentLight::build_cdf, main.cpp:97-120
+    // (sequential fp32 prefix sum; cdf[0] is left un-normalised as written)
+    if (environment && environment->width > 0) {
+        const int w = environment->width, h = environment->height;
+        f.env_cdf.resize((size_t)w * h);
+        auto lum = [](const vec3& c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; };
+        f.env_cdf[0] = lum(environment->get(0, 0));
+        for (int i = 1; i < w * h; i++) f.env_cdf[i] = f.env_cdf[i - 1] + lum(environment->get(i % w, i / w));
+        f.env_total = f.env_cdf[(size_t)w * h - 1];
+        for (int i = 1; i < w * h; i++) f.env_cdf[i] = f.env_cdf[i] / f.env_total;
+    }
+}
+
+bool Scene::upload(int dev) {
+    if (gpu_scene) {
+        rt_scene_destroy(gpu_scene);
+        gpu_scene = nullptr;
+    }
+    const FlatScene& f = flat_scene;
+    rt_scene_desc d{};
+    d.root_ref = f.root_ref;
+    d.n_pairs = (int64_t)f.pairs.size();
+    d.pairs = f.pairs.data();
+    d.n_tris = (int64_t)f.tris.size();
+    d.tris = f.tris.data();
+    d.normals = f.normals.data();
+    d.n_materials = (int32_t)f.materials.size();
+    d.materials = f.materials.data();
+    d.n_lights = (int32_t)f.lights.size();
+    d.lights = f.lights.data();
+    d.n_emissive_tris = (int32_t)f.emissive.size();
+    d.emissive_tris = f.emissive.data();
+    std::vector<float> env_rgb;
+    if (!f.env_cdf.empty()) {
+        const int w = environment->width, h = environment->height;
+        env_rgb.resize((size_t)w * h * 3);
+        for (int i = 0; i < w * h; i++) put3(&env_rgb[3 * (size_t)i], environment->get(i % w, i / w));
+        d.env_w = w;
+        d.env_h = h;
+        d.env_rgb = env_rgb.data();
+        d.env_cdf = f.env_cdf.data();
+        d.env_total = f.env_total;
+        d.env_offset = environment_offset;
+    }
+    device = dev;
+    if (rt_scene_create(&d, dev, &gpu_scene) != RT_OK) {
+        std::printf("Scene upload failed: %s\n", rt_last_error());
+        gpu_scene = nullptr;
+        return false;
+    }
+    return true;
+}
+
+void Scene::build_top_level_bvh() {
+    build_acceleration();
+    flatten();
+    upload(device);
+}
+
+bool Scene::closest_hit(Ray r, Intersection* res) const { // Scene.cpp:17-77 + Object.h:350-355
+    if (!gpu_scene) {
+        std::printf("Scene::closest_hit: scene is not on a GPU (call build_top_level_bvh first)\n");
+        return false;
+    }
+    rt_ray ray;
+    put3(ray.o, r.pos);
+    put3(ray.d, r.dir);
+    rt_hit hit;
+    if (rt_trace_closest(gpu_scene, &ray, 1, &hit) != RT_OK || hit.tri < 0) return false;
+    const MeshTriangle& T = sceneMergedMesh.triangles[hit.tri];
+    res->t = hit.t;
+    res->point = r.at(hit.t);
+    vec3 N = (1 - hit.u - hit.v) * sceneMergedMesh.verts[T.indicies[0]].normal + hit.u * sceneMergedMesh.verts[T.indicies[1]].normal +
+             hit.v * sceneMergedMesh.verts[T.indicies[2]].normal;
+    N = normalize(N);
+    res->front_face = dot(r.dir, N) < 0;
+    res->normal = res->front_face ? N : -N;
+    res->index = 0;
+    res->material = T.materialIndex < materials.size() ? materials[T.materialIndex] : nullptr;
+    res->w0 = -r.dir;
+    return true;
+}
+
+bool Scene::any_hit(Ray r) const { // declared at Scene.h:133, never defined in the reference
+    if (!gpu_scene) {
+        std::printf("Scene::any_hit: scene is not on a GPU (call build_top_level_bvh first)\n");
+        return false;
+    }
+    rt_ray ray;
+    put3(ray.o, r.pos);
+    put3(ray.d, r.dir);
+    float tmax = INFINITY;
+    uint8_t occ = 0;
+    if (rt_trace_any(gpu_scene, &ray, &tmax, 1, &occ) != RT_OK) return false;
+    return occ != 0;
+}
+
+// --------------------------------------------------------------- Renderer
+void Renderer::initalize(const Options& options) { // main.cpp:936-948
+    width = options.width;
+    height = options.height;
+    samples = options.samples_per_pixel;
+    final_buffer.assign((size_t)width * height * 3, 0);
+    radiance_sum.assign((size_t)width * height * 3, 0.f);
+}
+
+void Renderer::render_image(const Camera& cam, const Scene& scene, const Options& options) { // main.cpp:950-1020
+    initalize(options);
+    if (!scene.gpu()) {
+        std::printf("Renderer: scene is not on a GPU (call build_top_level_bvh first)\n");
+        return;
+    }
+    rt_camera c = cam.flatten();
+    rt_options o{};
+    o.width = width;
+    o.height = height;
+    o.spp_begin = 0;
+    o.spp_count = samples;
+    o.spp_total = samples;
+    o.max_depth = options.max_depth;
+    o.x0 = 0;
+    o.y0 = 0;
+    o.x1 = width;
+    o.y1 = height;
+    o.seed = options.seed;
+    o.spp_per_pass = options.spp_per_pass;
+    o.flags = RT_RENDER_CLEAR;
+    last_stats = rt_stats{};
+    if (rt_render(scene.gpu(), &c, &o, radiance_sum.data(), &last_stats) != RT_OK) {
+        std::printf("Renderer: %s\n", rt_last_error());
+        return;
+    }
+    if (rt_resolve(scene.gpu(), radiance_sum.data(), width, height, samples, options.gamma, final_buffer.data()) != RT_OK) {
+        std::printf("Renderer: %s\n", rt_last_error());
+        return;
+    }
+    std::printf("\nDONE, seconds elapsed: %g\n", last_stats.ms_total / 1000.0);
+    if (write_output && write_bmp(options.output_name, width, height, final_buffer.data()))
+        std::printf("Output written: %s\n", options.output_name.c_str());
+}
+
+bool write_bmp(const std::string& path, int w, int h, const uint8_t* rgb) {
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) return false;
+    const int row = (w * 3 + 3) & ~3;
+    const uint32_t size = 54 + (uint32_t)row * h;
+    uint8_t hdr[54] = {'B', 'M'};
+    auto put32 = [&](int at, uint32_t v) {
+        for (int i = 0; i < 4; i++) hdr[at + i] = (uint8_t)(v >> (8 * i));
+    };
+    put32(2, size);
+    put32(10, 54);
+    put32(14, 40);
+    put32(18, (uint32_t)w);
+    put32(22, (uint32_t)h);
+    hdr[26] = 1;
+    hdr[28] = 24;
+    put32(34, (uint32_t)row * h);
+    std::fwrite(hdr, 1, 54, fp);
+    std::vector<uint8_t> line(row, 0);
+    for (int y = h - 1; y >= 0; y--) { // BMP rows are bottom-up; buffer row 0 is the top (main.cpp:990)
+        for (int x = 0; x < w; x++) {
+            line[3 * x] = rgb[((size_t)y * w + x) * 3 + 2];
+            line[3 * x + 1] = rgb[((size_t)y * w + x) * 3 + 1];
+            line[3 * x + 2] = rgb[((size_t)y * w + x) * 3];
+        }
+        std::fwrite(line.data(), 1, row, fp);
+    }
+    std::fclose(fp);
+    return true;
+}
+
+// -------------------------------------------------------------- materials
+Material* material_from_record(const rt_material& r) {
+    vec3 c0(r.c0[0], r.c0[1], r.c0[2]), c1(r.c1[0], r.c1[1], r.c1[2]);
+    switch (r.type) {
+    case RT_MAT_MATTE: return new MatteMaterial(new ConstantTexture(c0));
+    case RT_MAT_MICROFACET_GGX: return new Microfacet(nullptr, r.s[0], r.s[1]);
+    case RT_MAT_MICROFACET_BECKMANN: return new BeckmannMicrofacet(nullptr, r.s[0], r.s[1]);
+    case RT_MAT_EMISSIVE: return new EmissiveMaterial(c0);
+    case RT_MAT_DISNEY_DIFFUSE: return new DisneyDiffuse(c0, r.s[0], r.s[1]);
+    case RT_MAT_DISNEY_METAL: return new DisneyMetal(c0, r.s[0], r.s[1]);
+    case RT_MAT_DISNEY_CLEARCOAT: return new DisneyClearcoat(r.s[0]);
+    case RT_MAT_DISNEY_GLASS: return new DisneyGlass(c0, r.s[0], r.s[1], r.s[2]);
+    case RT_MAT_ROUGH_DIELECTRIC: return new RoughDielectric(r.s[0], r.s[1], c0, c1);
+    case RT_MAT_DISNEY_SHEEN: return new DisneySheen(c0, r.s[0]);
+    case RT_MAT_DISNEY_UBER: {
+        DisneyUber* u = new DisneyUber;
+        u->base_color = c0;
+        u->specular_transmission = r.s[0]; u->metallic = r.s[1]; u->subsurface = r.s[2]; u->specular = r.s[3];
+        u->roughness = r.s[4]; u->specular_tint = r.s[5]; u->anisotropic = r.s[6]; u->sheen = r.s[7];
+        u->sheen_tint = r.s[8]; u->clearcoat = r.s[9]; u->clearcoat_gloss = r.s[10]; u->ior = r.s[11];
+        return u;
+    }
+    case RT_MAT_GLASS: return new GlassMaterial(r.s[0]);
+    default: return nullptr;
+    }
+}
+
+} // namespace rt

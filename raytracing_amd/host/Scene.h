@@ -1,0 +1,210 @@
+// Scene.h — host mirror of the reference's scene-side API (target design):
+// Camera (Scene.h:10-81), Scene (Scene.h:103-153), Intersection (Def.h:11-40),
+// Filter (Filter.h), Image (Image.h), the Rectangle light Instance
+// (Object.h:61-135,364-423) and Options/Renderer (main.cpp:836-1020).
+// Queries and rendering are forwarded to librt_hip.so through include/rt_hip.h.
+#pragma once
+#include "../../include/rt_hip.h"
+#include "Material.h"
+#include "Mesh.h"
+#include <string>
+#include <vector>
+
+namespace rt {
+
+struct Intersection { // Def.h:11-40
+    vec3 point, normal, w0;
+    float t = 0;
+    bool front_face = true;
+    float u = 0, v = 0;
+    int index = 0;
+    const Material* material = nullptr;
+};
+
+class Filter { // Filter.h:5-10
+public:
+    virtual ~Filter() {}
+    virtual vec2 sample(float dx, float dy) const = 0;
+    virtual void describe(int32_t* kind, float* param) const = 0;
+};
+class BoxFilter : public Filter { // Filter.h:12-27
+public:
+    explicit BoxFilter(float width_) : width(width_) {}
+    vec2 sample(float dx, float dy) const override;
+    void describe(int32_t* kind, float* param) const override { *kind = RT_FILTER_BOX; *param = width; }
+    float width;
+};
+class GaussianFilter : public Filter { // Filter.h:28-42
+public:
+    explicit GaussianFilter(float stddev_) : stddev(stddev_) {}
+    vec2 sample(float dx, float dy) const override;
+    void describe(int32_t* kind, float* param) const override { *kind = RT_FILTER_GAUSSIAN; *param = stddev; }
+    float stddev;
+};
+
+class Camera { // Scene.h:10-81
+public:
+    Camera() {}
+    Camera(const mat4& view_matrix, float fov, int width, int height, Filter* filter = nullptr);
+    ~Camera() { delete filter; }
+    Camera(const Camera&) = delete;
+    Camera& operator=(const Camera&) = delete;
+    Camera& operator=(Camera&& other);
+    Ray get_ray(float raster_x, float raster_y) const;
+    rt_camera flatten() const;
+
+    Filter* filter = nullptr;
+    vec3 camera_pos;
+    mat4 raster_to_world;
+};
+
+class Image { // Image.h:7-69 (float RGB only on this path)
+public:
+    enum class Format { None, RGBA_32f, RGB_32f, RGBA_u8, RGB_u8 };
+    vec3 get(int x, int y) const;
+    int width = 0, height = 0;
+    std::vector<char> imageData;
+    Format internalFormat = Format::None;
+};
+using HDRImage = Image;
+HDRImage* make_uniform_environment(int width, int height, vec3 radiance);
+
+class Geometry { // Object.h:9-24
+public:
+    virtual ~Geometry() {}
+    virtual float area() const { return 0.f; }
+};
+class Rectangle : public Geometry { // Object.h:61-135
+public:
+    Rectangle(vec3 normal, vec3 tangent, float u_length, float v_length);
+    Rectangle(vec3 normal, float u_length, float v_length);
+    float area() const override { return (2 * u) * (2 * v); }
+    vec3 N, T, B;
+    float u, v; // half side lengths
+};
+class Instance { // Object.h:364-423
+public:
+    Instance(Geometry* geo, Material* mat, vec3 offset) : geometry(geo), material(mat), transform(translate(mat4(1.f), offset)) {}
+    Instance(Geometry* geo, Material* mat, mat4 m) : geometry(geo), material(mat), transform(m) {}
+    void free_data() {
+        delete geometry;
+        delete material;
+    }
+    float get_area() const { return geometry->area(); }
+    const Material* get_material() const { return material; }
+    const Geometry* get_geometry() const { return geometry; }
+    const Transform& get_transform() const { return transform; }
+
+private:
+    Geometry* geometry = nullptr;
+    Material* material = nullptr;
+    Transform transform;
+};
+
+// How glTF pbrMetallicRoughness materials become reference materials
+// (Scene::load_gltf_materials is declared but unwritten: Scene.cpp:174).
+enum GltfMaterialMode {
+    GLTF_MATERIALS_UBER = 0,  // DisneyUber{base, metallic, roughness, transmission}
+    GLTF_MATERIALS_MATTE = 1, // MatteMaterial(baseColor)
+    GLTF_MATERIALS_GGX = 2    // roughness>0 && !transmission -> Microfacet (even material index) / BeckmannMicrofacet (odd)
+};
+
+// The flattened, GPU-ready arrays (what rt_scene_create uploads).
+struct FlatScene {
+    int32_t root_ref = -1;
+    std::vector<rt_bvh_pair> pairs;
+    std::vector<rt_tri> tris;
+    std::vector<rt_tri_normals> normals;
+    std::vector<rt_material> materials;
+    std::vector<rt_light> lights;
+    std::vector<rt_emissive_tri> emissive;
+    std::vector<int32_t> tri_light;       // per ORIGINAL triangle: light index or -1
+    std::vector<int32_t> emissive_orig;   // emissive[i].slot's original triangle index
+    std::vector<float> env_cdf;
+    float env_total = 0;
+};
+
+class Scene { // Scene.h:103-153
+public:
+    Scene() {}
+    ~Scene();
+    Scene(const Scene&) = delete;
+    Scene& operator=(const Scene&) = delete;
+
+    bool load_from_gltf(const std::string& gltfPath);
+    bool closest_hit(Ray r, Intersection* res) const;
+    bool any_hit(Ray r) const;
+    // Scene.cpp:6-15 in the legacy design built the TLAS.  In the target design
+    // (one merged mesh) it builds the mesh BVH, derives the light tables,
+    // flattens everything and uploads it to the GPU once.
+    void build_top_level_bvh();
+
+    // Adds the Instance(Rectangle, EmissiveMaterial, transform) pair the
+    // reference pushes into both `instances` and `lights` (main.cpp:801-813):
+    // two emissive triangles into sceneMergedMesh + the sampled light.
+    void add_rectangle_light(vec3 normal, float u_length, float v_length, vec3 emit, const mat4& transform);
+    void set_environment(HDRImage* img, float degrees_offset = 0.f); // takes ownership
+
+    // stages of build_top_level_bvh, exposed for tests and for hosts without a GPU
+    void build_acceleration(int max_per_leaf = 1, PartitionStrategy strat = BVH_SAH);
+    void flatten();
+    bool upload(int device);
+    rt_scene* gpu() const { return gpu_scene; }
+    const FlatScene& flat() const { return flat_scene; }
+
+    bool hasCamera = false;
+    Camera sceneCamera;
+    mat4 sceneCameraView = mat4(1.f); // view matrix + vertical fov the camera was built from,
+    float sceneCameraFov = 39.6f;     // so a host can rebuild it at another resolution
+    Mesh sceneMergedMesh;
+    std::vector<Material*> materials;
+    std::vector<Image*> images;
+    std::vector<Instance> lights;
+    vec3 background_color = vec3(0);
+
+    HDRImage* environment = nullptr;
+    float environment_offset = 0.f; // degrees / 360 (main.cpp:94)
+    GltfMaterialMode gltf_material_mode = GLTF_MATERIALS_UBER;
+    float gltf_emissive_scale = 1.f;
+    int device = 0;
+
+private:
+    FlatScene flat_scene;
+    rt_scene* gpu_scene = nullptr;
+    std::vector<int> light_first_tri; // per rect light: first of its two triangles
+};
+
+struct Options { // main.cpp:836-850
+    std::string output_name = "Output.bmp";
+    int num_threads = 0; // unused on the GPU path
+    int width = 512, height = 512;
+    int samples_per_pixel = 1;
+    int max_depth = 4;
+    int direct_samples = 1;
+    int tile_size = 16; // unused on the GPU path
+    float gamma = 2.2f;
+    unsigned seed = 0;
+    int spp_per_pass = 0;
+};
+
+class Renderer { // main.cpp:853-903,950-1020
+public:
+    void initalize(const Options& options);
+    // Drop-in for the reference's render call: same signature, the thread pool
+    // replaced by rt_render + rt_resolve on the scene's GPU.
+    void render_image(const Camera& cam, const Scene& scene, const Options& options);
+
+    const std::vector<uint8_t>& pixels() const { return final_buffer; }
+    const std::vector<float>& radiance() const { return radiance_sum; }
+    rt_stats last_stats{};
+    bool write_output = true;
+
+private:
+    int width = 0, height = 0, samples = 0;
+    std::vector<uint8_t> final_buffer;
+    std::vector<float> radiance_sum;
+};
+
+bool write_bmp(const std::string& path, int w, int h, const uint8_t* rgb);
+
+} // namespace rt

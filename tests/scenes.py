@@ -1,0 +1,119 @@
+"""Scene builders shared by the tests, smoke() and bench.py (synthetic data only)."""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CORNELL_GLB = os.path.join(ROOT, "tests", "golden", "cornellbox.glb")
+
+
+def _quad(rta, corners, normal, material):
+    v = np.zeros(4, rta.VERTEX)
+    v["pos"] = np.asarray(corners, np.float32)
+    v["normal"] = np.asarray(normal, np.float32)
+    v["uv"] = [(0, 0), (1, 0), (1, 1), (0, 1)]
+    t = np.zeros(2, rta.TRIANGLE)
+    t["idx"] = [(0, 1, 2), (0, 2, 3)]
+    t["material"] = material
+    return v, t
+
+
+def _box(rta, lo, hi, material):
+    lo, hi = np.asarray(lo, np.float32), np.asarray(hi, np.float32)
+    x0, y0, z0 = lo
+    x1, y1, z1 = hi
+    faces = [
+        ([(x0, y0, z1), (x1, y0, z1), (x1, y1, z1), (x0, y1, z1)], (0, 0, 1)),
+        ([(x1, y0, z0), (x0, y0, z0), (x0, y1, z0), (x1, y1, z0)], (0, 0, -1)),
+        ([(x1, y0, z1), (x1, y0, z0), (x1, y1, z0), (x1, y1, z1)], (1, 0, 0)),
+        ([(x0, y0, z0), (x0, y0, z1), (x0, y1, z1), (x0, y1, z0)], (-1, 0, 0)),
+        ([(x0, y1, z1), (x1, y1, z1), (x1, y1, z0), (x0, y1, z0)], (0, 1, 0)),
+        ([(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1)], (0, -1, 0)),
+    ]
+    return [_quad(rta, c, n, material) for c, n in faces]
+
+
+def quad_room(rta, box_material=None, light=True, env=0.05, tall_material=None):
+    """A 2x2x2 Cornell-style room (open towards +z) with a rectangle light under the ceiling, one box with a
+    configurable material (default GGX roughness 0.4) and a second, tall, Lambert box.  82 triangles."""
+    sc = rta.Scene()
+    white = sc.add_material(rta.material(rta.MAT_MATTE, (0.725, 0.71, 0.68)))
+    red = sc.add_material(rta.material(rta.MAT_MATTE, (0.63, 0.065, 0.05)))
+    green = sc.add_material(rta.material(rta.MAT_MATTE, (0.14, 0.45, 0.091)))
+    boxm = sc.add_material(box_material if box_material is not None else rta.material(rta.MAT_GGX, s=(0.4, 0.0)))
+    tallm = sc.add_material(tall_material if tall_material is not None else rta.material(rta.MAT_MATTE, (0.6, 0.6, 0.7)))
+    parts = [
+        _quad(rta, [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)], (0, 1, 0), white),     # floor
+        _quad(rta, [(-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)], (0, -1, 0), white),    # ceiling
+        _quad(rta, [(-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)], (0, 0, 1), white),   # back
+        _quad(rta, [(-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)], (1, 0, 0), red),     # left
+        _quad(rta, [(1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)], (-1, 0, 0), green),      # right
+    ]
+    parts += _box(rta, (0.15, 0.0, -0.1), (0.7, 0.6, 0.45), boxm)
+    parts += _box(rta, (-0.7, 0.0, -0.65), (-0.15, 1.2, -0.1), tallm)
+    # a strip of many small triangles on the floor so the BVH has some depth
+    n = 6
+    for i in range(n):
+        for j in range(n):
+            x0, z0 = -0.9 + 0.1 * i, 0.3 + 0.1 * j
+            parts.append(_quad(rta, [(x0, 0.01, z0 + 0.08), (x0 + 0.08, 0.01, z0 + 0.08), (x0 + 0.08, 0.01, z0), (x0, 0.01, z0)],
+                               (0, 1, 0), white if (i + j) % 2 else red))
+    for v, t in parts:
+        sc.add_mesh(v, t)
+    if light:
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = (0.0, 1.98, 0.0)
+        sc.add_rect_light((0, -1, 0), 0.6, 0.5, (17, 12, 4), m.T.reshape(-1))  # column-major
+    if env is not None:
+        sc.set_env(np.full((8, 16, 3), env, np.float32))
+    return sc
+
+
+def random_triangles(rta, n, seed=1234, material=None):
+    """BASELINE config 3 geometry: n triangles, centres uniform in [0,1]^3, vertices = centre + U(-s/2, s/2)^3,
+    s = 0.5 n^(-1/3); one Lambert material, one rect light at the box top."""
+    rng = np.random.default_rng(seed)
+    s = 0.5 * n ** (-1.0 / 3.0)
+    c = rng.random((n, 1, 3), dtype=np.float32)
+    p = (c + (rng.random((n, 3, 3), dtype=np.float32) - 0.5) * s).astype(np.float32)
+    v = np.zeros(3 * n, rta.VERTEX)
+    v["pos"] = p.reshape(-1, 3)
+    e1, e2 = p[:, 1] - p[:, 0], p[:, 2] - p[:, 0]
+    nn = np.cross(e1, e2)
+    nn /= np.maximum(np.linalg.norm(nn, axis=1, keepdims=True), 1e-20)
+    v["normal"] = np.repeat(nn, 3, axis=0)
+    t = np.zeros(n, rta.TRIANGLE)
+    t["idx"] = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    sc = rta.Scene()
+    sc.add_material(material if material is not None else rta.material(rta.MAT_MATTE, (0.7, 0.7, 0.7)))
+    sc.add_mesh(v, t)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = (0.5, 1.2, 0.5)
+    sc.add_rect_light((0, -1, 0), 0.5, 0.5, (20, 20, 20), m.T.reshape(-1))
+    return sc
+
+
+def cornellbox(rta, mode=None, emissive_scale=15.0, env=0.02):
+    """cornellbox.glb (data asset of the reference, committed under tests/golden/) through Scene::load_from_gltf.
+    mode: a raytracing_amd GLTF_* material mode (default GLTF_GGX: the BASELINE config-2 GGX + Beckmann mix)."""
+    sc = rta.Scene()
+    sc.load_gltf(CORNELL_GLB, rta.GLTF_GGX if mode is None else mode, emissive_scale)
+    if env is not None:
+        sc.set_env(np.full((8, 16, 3), env, np.float32))
+    return sc
+
+
+def cornell_camera(rta, sc, width, height):
+    info = sc.info()
+    return rta.camera(info["camera_view"], info["camera_fov"], width, height)
+
+
+def random_rays(n, seed, lo=(-0.2, -0.2, -0.2), hi=(1.2, 1.2, 1.2)):
+    """Incoherent rays: origins uniform in a box, directions uniform on the sphere."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros(n, np.dtype([("o", "<f4", 3), ("d", "<f4", 3)]))
+    rays["o"] = (np.asarray(lo) + rng.random((n, 3)) * (np.asarray(hi) - np.asarray(lo))).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays["d"] = d.astype(np.float32)
+    return rays

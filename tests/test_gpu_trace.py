@@ -1,0 +1,128 @@
+"""-m gpu: closest-hit / any-hit parity of the HIP traversal kernels against the oracle, through the C-ABI.
+Bar: triangle ids and occlusion flags bit-exact; t, u, v bit-exact too (same fp32 recipe, fp-contract off) —
+stricter than the north star's 1e-5 relative."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _secondary_rays(orc, osc, rays, hits, seed):
+    """Bounce rays leaving the primary hit points in random directions (incoherent)."""
+    ok = hits["tri"] >= 0
+    p = rays["o"][ok] + rays["d"][ok] * hits["t"][ok, None]
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=p.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    out = np.zeros(len(p), orc.RAY)
+    out["o"] = (p + 1e-3 * d).astype(np.float32)
+    out["d"] = d.astype(np.float32)
+    return out
+
+
+def _check_closest(sc, orc, osc, rays):
+    got = sc.trace_closest(rays)
+    want, _ = orc.closest_hit(osc, rays)
+    assert np.array_equal(got["tri"], want["tri"]), f"{np.count_nonzero(got['tri'] != want['tri'])} triangle ids differ"
+    hit = want["tri"] >= 0
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit], want[f][hit]), f"{f} differs"
+    return want
+
+
+@pytest.fixture(scope="module")
+def room(rta, orc, gpu):
+    sc = scenes.quad_room(rta)
+    sc.build()
+    sc.upload(gpu)
+    return sc, orc.scene_from_host(sc, own_bvh=True)
+
+
+@pytest.fixture(scope="module")
+def cornell(rta, orc, gpu):
+    sc = scenes.cornellbox(rta)
+    sc.build()
+    sc.upload(gpu)
+    return sc, orc.scene_from_host(sc)
+
+
+def test_closest_primary_and_secondary_room(rta, orc, room):
+    sc, osc = room
+    cam = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, 96, 96)
+    rays = orc.camera_rays(cam, 96, 96, 3, 16)
+    hits = _check_closest(sc, orc, osc, rays)
+    assert (hits["tri"] >= 0).mean() > 0.5
+    _check_closest(sc, orc, osc, _secondary_rays(orc, osc, rays, hits, 1))
+
+
+def test_closest_cornellbox(rta, orc, cornell):
+    sc, osc = cornell
+    cam = scenes.cornell_camera(rta, sc, 128, 128)
+    rays = orc.camera_rays(cam, 128, 128, 0, 4)
+    hits = _check_closest(sc, orc, osc, rays)
+    sec = _secondary_rays(orc, osc, rays, hits, 2)
+    hits2 = _check_closest(sc, orc, osc, sec)
+    _check_closest(sc, orc, osc, _secondary_rays(orc, osc, sec, hits2, 3))
+    _check_closest(sc, orc, osc, scenes.random_rays(20000, 5, lo=(-1.7, 0, -1.7), hi=(1.7, 3.4, 1.7)))
+
+
+def test_any_hit(rta, orc, cornell):
+    sc, osc = cornell
+    rays = scenes.random_rays(30000, 11, lo=(-1.7, 0, -1.7), hi=(1.7, 3.4, 1.7))
+    rng = np.random.default_rng(12)
+    tmax = rng.random(len(rays)).astype(np.float32) * 3.0
+    tmax[::7] = np.inf
+    got = sc.trace_any(rays, tmax)
+    want = orc.any_hit(osc, rays, tmax)
+    assert np.array_equal(got, want)
+    assert 0.05 < want.mean() < 0.95
+
+
+def test_edge_cases(rta, orc, gpu):
+    """One-triangle scene (root is a leaf), axis-parallel rays (inf/NaN slabs), rays starting on a surface,
+    empty batch, leaves with several triangles."""
+    sc = rta.Scene()
+    sc.add_material(rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5)))
+    v = np.zeros(3, rta.VERTEX)
+    v["pos"] = [(-1, -1, -4), (1, -1, -4), (0, 1, -4)]
+    v["normal"] = (0, 0, 1)
+    t = np.zeros(1, rta.TRIANGLE)
+    t["idx"] = [(0, 1, 2)]
+    sc.add_mesh(v, t)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.scene_from_host(sc)
+    rays = np.zeros(3, rta.RAY)
+    rays["d"] = [(0, 0, -1), (0, 0, 1), (0.3, 0, -1)]
+    hits = _check_closest(sc, orc, osc, rays)
+    assert hits["tri"][0] == 0 and hits["t"][0] == 4.0 and hits["tri"][1] == -1
+    assert len(sc.trace_closest(np.zeros(0, rta.RAY))) == 0
+
+    room = scenes.quad_room(rta)
+    room.build(max_per_leaf=4, strategy=0)  # BVH_MIDDLE, multi-triangle leaves
+    room.upload(gpu)
+    oroom = orc.scene_from_host(room)
+    rays = scenes.random_rays(5000, 3, lo=(-1, 0, -1), hi=(1, 2, 1))
+    rays["d"][::5] = (0, -1, 0)   # axis-parallel: 1/0 = inf in the slab test
+    rays["d"][1::5] = (1, 0, 0)
+    rays["o"][2::5, 1] = 0.0      # origins lying in the floor plane
+    _check_closest(room, orc, oroom, rays)
+    tmax = np.full(len(rays), np.inf, np.float32)
+    assert np.array_equal(room.trace_any(rays, tmax), orc.any_hit(oroom, rays, tmax))
+
+
+def test_host_scene_api(rta, orc, room):
+    """Scene::closest_hit / Scene::any_hit (the reference's query seam) for single rays."""
+    sc, osc = room
+    ray = np.zeros(1, rta.RAY)
+    ray["o"] = (0, 1, 3.2)
+    ray["d"] = (0, 0, -1)
+    hit = sc.closest_hit(ray)
+    want, _ = orc.closest_hit(osc, ray)
+    assert hit is not None and hit["t"] == want["t"][0]
+    assert hit["front_face"] and np.allclose(hit["normal"], (0, 0, 1))
+    assert sc.any_hit(ray)
+    ray["d"] = (0, 0, 1)
+    assert sc.closest_hit(ray) is None and not sc.any_hit(ray)
