@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the path-tracing hot path (BASELINE.json configs[1]).
+
+Workload: cornellbox.glb (13 170 triangles) at 1920x1080, 8 bounces, GGX + Beckmann material mapping, camera from the
+file's Camera node chain, uniform 16x8 environment.  One "step" = one rt_render call tracing SPP_STEP samples per pixel
+of a (steps x SPP_STEP x n_gpus)-sample Hammersley set; the default 64 steps x 16 spp = the configuration's 1024 spp.
+Multi-GPU: sample-pass sharding — rank r renders its own window of sample indices (no data-path collective) and ONE
+RCCL reduce of the fp32 radiance buffer to rank 0 closes the frame (inside the timed region).
+
+Prints ONE JSON line on rank 0.  `value` = (closest-hit + shadow rays actually traced, all ranks) / wall seconds, rays
+counted by device counters, radiance accumulated in HBM (device output, nothing crosses PCIe in the timed region)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 16
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+VISITS_JSON = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
+
+
+def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
+    """The oracle (CPU restatement, kind "port") timed on this host on a bounded sample of the same workload."""
+    import oracle_bindings as orc
+
+    osc = orc.scene_from_host(sc)
+    cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
+    cores = min(16, os.cpu_count() or 1)
+    tile = (720, 405, 1200, 675)  # central 480x270 window of the 1080p raster
+    spp = 1
+    total = {"rays_closest": 0, "rays_shadow": 0, "paths": 0, "seconds": 0.0}
+    done = 0
+    # double the sample count until ~seconds_target of CPU time has been spent
+    while total["seconds"] < seconds_target and done < 1024:
+        _, c = orc.render(osc, cam, WIDTH, HEIGHT, spp, DEPTH, seed=1, spp_begin=done, spp_total=1024, tile=tile, threads=cores)
+        for k in total:
+            total[k] += c[k]
+        done += spp
+        spp = min(spp * 2, 1024 - done) or 1
+    rays = total["rays_closest"] + total["rays_shadow"]
+    return {
+        "value": rays / total["seconds"] / 1e6,
+        "unit": "Mrays/s",
+        "cores": cores,
+        "kind": "port",
+        "samples_per_s": total["paths"] / total["seconds"],
+        "sample": f"oracle/ CPU restatement, {cores} threads, thread-local counter RNG, 480x270 central tile of the 1080p "
+                  f"raster, {done} spp, depth {DEPTH}: {total['paths']} paths, {rays} rays in {total['seconds']:.1f} s",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import raytracing_amd as rta
+    import scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if rta.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- scene: load, build the BVH on the host, flatten, upload once
+    t0 = time.time()
+    sc = scenes.cornellbox(rta)
+    sc.build()
+    t_build = time.time() - t0
+    sc.upload(local_rank)
+    cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
+
+    K, W = args.steps, args.warmup
+    spp_total = K * SPP_STEP * world
+    first = rank * K * SPP_STEP  # this rank's window of the Hammersley set
+    frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+
+    def step(i, timing):
+        _, st = sc.render(cam, WIDTH, HEIGHT, spp=SPP_STEP, max_depth=DEPTH, seed=1, spp_begin=first + (i % K) * SPP_STEP,
+                          spp_total=spp_total, spp_per_pass=args.spp_per_pass, device_out=frame.data_ptr(), timing=timing)
+        return st
+
+    for i in range(W):
+        step(i, False)
+    frame.zero_()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = None
+    for i in range(K):
+        st = step(i, True)
+        if stats is None:
+            stats = dict(st)
+        else:
+            for k in st:
+                stats[k] += st[k]
+    if world > 1:
+        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # the frame's single RCCL reduce over xGMI
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    totals = torch.tensor([elapsed, float(stats["rays_closest"]), float(stats["rays_shadow"]), float(stats["paths"])],
+                          dtype=torch.float64, device=f"cuda:{local_rank}")
+    if world > 1:
+        tmax = totals[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        totals[0] = tmax[0]
+    elapsed, rays_c, rays_s, paths = [float(x) for x in totals.tolist()]
+
+    if rank == 0:
+        rays = rays_c + rays_s
+        out = {
+            "metric": "Mrays/s and samples/s per GPU (1/2/4/8 MI355X), 1080p cornellbox, 8 bounces",
+            "value": rays / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "samples_per_s": paths / elapsed,
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed * 1000.0 / K,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"cornellbox.glb {WIDTH}x{HEIGHT}, {DEPTH} bounces, GGX+Beckmann materials, {SPP_STEP} spp per step, "
+                            f"{K * SPP_STEP} spp per GPU ({spp_total}-sample Hammersley set), sample-pass sharding + one reduce",
+                "triangles": int(len(sc.array(rta.ARR_TRIS))),
+                "rays_closest": rays_c,
+                "rays_shadow": rays_s,
+                "rays_per_sample": rays / paths,
+                "bvh_build_s": t_build,
+                "frame_mean": float(frame.mean().item()) / (K * SPP_STEP * world),
+            },
+        }
+        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
+        visits = json.load(open(VISITS_JSON)) if os.path.exists(VISITS_JSON) else None
+        kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"
+        if visits:
+            v = visits["closest" if kern == "k_closest" else "shadow"]
+            n_rays = stats["rays_closest"] if kern == "k_closest" else stats["rays_shadow"]
+            ms = stats["ms_closest"] if kern == "k_closest" else stats["ms_shadow"]
+            launches = stats["launches_closest"] if kern == "k_closest" else stats["launches_shadow"]
+            gbps = n_rays * v["bytes_per_ray"] / (ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                "traffic": None, "kernel": kern, "bytes_per_ray": v["bytes_per_ray"], "rays_per_launch": n_rays / max(launches, 1),
+                "avg_launch_ms": ms / max(launches, 1), "launches": launches,
+            }
+        out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scenes, rta, sc)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

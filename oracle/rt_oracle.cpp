@@ -987,13 +987,17 @@ V3 env_sample(const orc_scene* s, float rnd, V3* dir, float* pdf) { // main.cpp:
 // ------------------------------------------------------------- integrator
 struct Ctx {
     const orc_scene* s;
-    uint64_t rays_closest = 0, rays_shadow = 0, inner = 0, leaf = 0;
+    uint64_t rays_closest = 0, rays_shadow = 0, inner = 0, leaf = 0, s_inner = 0, s_leaf = 0;
 };
 
 bool occluded(Ctx& c, const V3& o, const V3& d, float tmin, float tmax) {
     c.rays_shadow++;
     MeshHit h;
-    return mesh_traverse(c.s, o, d, tmin, tmax, true, h, nullptr);
+    orc_visits vis;
+    bool hit = mesh_traverse(c.s, o, d, tmin, tmax, true, h, &vis);
+    c.s_inner += vis.inner;
+    c.s_leaf += vis.leaf;
+    return hit;
 }
 
 // Instance::sample_geometry for a light (Object.h:396-403,124-131) + TRIMESH extension
@@ -1317,6 +1321,8 @@ void orc_radiance(const orc_scene* s, const orc_camera* cam, const orc_options* 
         c->rays_shadow += ctx.rays_shadow;
         c->inner_visits += ctx.inner;
         c->leaf_visits += ctx.leaf;
+        c->shadow_inner_visits += ctx.s_inner;
+        c->shadow_leaf_visits += ctx.s_leaf;
         c->paths += 1;
     }
 }
@@ -1360,6 +1366,8 @@ void orc_render(const orc_scene* s, const orc_camera* cam, const orc_options* o,
             c->rays_shadow += ctx.rays_shadow;
             c->inner_visits += ctx.inner;
             c->leaf_visits += ctx.leaf;
+            c->shadow_inner_visits += ctx.s_inner;
+            c->shadow_leaf_visits += ctx.s_leaf;
             c->paths += paths;
         }
     };

@@ -116,6 +116,8 @@ typedef struct orc_counters {
     uint64_t inner_visits; /* closest-hit traversal only */
     uint64_t leaf_visits;
     double seconds;
+    uint64_t shadow_inner_visits; /* shadow (any-hit) traversal */
+    uint64_t shadow_leaf_visits;
 } orc_counters;
 
 /* BVH.cpp:5-149.  nodes must hold 2n entries, indices n.  Returns node count. */

@@ -38,7 +38,8 @@ class OrcOptions(C.Structure):
 
 class OrcCounters(C.Structure):
     _fields_ = [("rays_closest", C.c_uint64), ("rays_shadow", C.c_uint64), ("paths", C.c_uint64),
-                ("inner_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("seconds", C.c_double)]
+                ("inner_visits", C.c_uint64), ("leaf_visits", C.c_uint64), ("seconds", C.c_double),
+                ("shadow_inner_visits", C.c_uint64), ("shadow_leaf_visits", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
