@@ -69,6 +69,7 @@ def main():
 
     import raytracing_amd as rta
     import scenes
+    from raytracing_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -91,8 +92,7 @@ def main():
     cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
 
     K, W = args.steps, args.warmup
-    spp_total = K * SPP_STEP * world
-    first = rank * K * SPP_STEP  # this rank's window of the Hammersley set
+    first, _, spp_total = sharding.sample_window(rank, world, K * SPP_STEP)  # this rank's window of the Hammersley set
     frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step(i, timing):
@@ -116,8 +116,7 @@ def main():
         else:
             for k in st:
                 stats[k] += st[k]
-    if world > 1:
-        dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # the frame's single RCCL reduce over xGMI
+    sharding.reduce_frame(frame, dst=0)  # the frame's single RCCL reduce over xGMI (no-op at world 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -3,6 +3,8 @@ Test infrastructure only: nothing under raytracing_amd/ imports this."""
 import ctypes as C
 import os
 
+import ctypes as C  # noqa: F401 (re-exported for tests)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
