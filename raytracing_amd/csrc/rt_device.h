@@ -82,8 +82,11 @@ struct SceneView {
     const float* env_cdf;
     int32_t root_ref;
     int32_t n_lights;
+    int32_t n_emissive;
     int32_t env_w, env_h;
     float env_total, env_offset;
+    int32_t refill_min; // refill a wave's idle lanes once this many are idle
+    int32_t leaf_min;   // test pending leaves once this many lanes wait at one (or no lane has an inner node)
 };
 
 // Bounds::intersect, Math.h:755-770
@@ -98,30 +101,94 @@ RT_DEV bool slab(const V3& bmin, const V3& bmax, const V3& o, const V3& inv, flo
     return !(tnear > tfar || tfar < 0.f);
 }
 
-// Closest-hit (ANY = false: TriangleMesh::intersect, Object.h:273-344) or
-// boolean occlusion (ANY = true: trace_scene as used at main.cpp:250,281).
-// One ray per lane; the traversal stack keeps its first RT_SHORT_STACK entries
-// in LDS (column `lds[entry * RT_BLOCK]`, conflict-free across lanes) and spills
-// deeper entries to private memory.  Visit order, culling rule (`dist < t`, not
-// re-tested at pop) and the accept-on-equal-t rule are the reference's.
-template <bool ANY>
-RT_DEV bool traverse(const SceneView& sc, const V3& o, const V3& d, float tmax, int* lds, int& hit_slot, float& hit_t,
-                     float& hit_u, float& hit_v) {
+#define RT_CUR_DONE ((int)0x80000000)   // lane has no ray
+#define RT_CUR_FINISH ((int)0x80000001) // lane's ray is complete, result not yet written
+
+struct RayState {
+    V3 o, d, inv;
+    float tmax;  // shrinking upper bound on accepted t (Object.h:314)
+    float t;     // best hit so far, INF before the first (Object.h:281)
+    float u, v;
+    int slot;    // best hit's triangle slot, -1 = none
+    uint32_t q;  // queue position of this ray
+};
+
+// Closest-hit (ANY = false: TriangleMesh::intersect, Object.h:273-344) or boolean occlusion (ANY = true:
+// trace_scene as used at main.cpp:250,281) over a dense ray queue, as PERSISTENT wave64s:
+//   * every wave refills its idle lanes from its own share of the queue, so lanes whose ray ended early do not idle
+//     until the slowest ray of their wave is done.  The share is static and interleaved — wave w of W owns the 64-ray
+//     groups w, w+W, w+2W, ... — so no atomic is needed (one shared cursor saturates at ~88 fetches/us on MI355X,
+//     which measured slower than no refill at all) and refills of whole groups stay coalesced;
+//   * "while-while" order: all lanes walk inner nodes until none has one pending, then all pending leaves are
+//     tested together — the two bodies are not interleaved per step under partial masks;
+//   * the traversal stack keeps its first RT_SHORT_STACK entries in LDS (column lds[entry * RT_BLOCK]: lanes of a
+//     wave hit consecutive banks) and spills deeper entries to private memory, up to the reference's 64.
+// Per ray the visit order, the culling rule (`dist < t` at push time, not re-tested at pop), right-child-first on
+// ties and accept-on-equal-t are exactly the reference's, so results do not depend on how rays share a wave.
+// sink(ray state) is called once per ray when it completes (RayState::q = its global queue index).  Exit: a wave's private cursor only grows, so it stops
+// fetching once its next group starts past `count` and leaves the loop when its last lane finishes.
+template <bool ANY, class Sink>
+RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                        const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap, int* lds, Sink sink) {
     int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
+    const uint32_t lane = __lane_id();
+    RayState r;
+    r.q = 0;
+    r.slot = -1;
+    r.t = INFINITY;
+    r.tmax = INFINITY;
+    r.u = r.v = 0.f;
+    r.o = r.d = r.inv = V3(0.f);
+    int cur = RT_CUR_DONE;
     int sp = 0;
-    const V3 inv(1.f / d.x, 1.f / d.y, 1.f / d.z);
-    float t = INFINITY;
-    int cur = sc.root_ref;
-    hit_slot = -1;
+    bool exhausted = false; // wave-uniform
+    // The queue is n_shards dense sub-queues (shard s = entries [s*shard_cap, s*shard_cap + counts[s])): the shade
+    // kernel fills them through n_shards counters so that no single address takes every reservation atomic.
+    // Wave g works on shard g % n_shards; the launch has a multiple of n_shards waves.
+    const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RT_BLOCK / 64) + threadIdx.x / 64));
+    const uint32_t shard = gwave % n_shards;
+    const uint32_t wave_id = gwave / n_shards;
+    const uint32_t n_waves = (gridDim.x * (RT_BLOCK / 64)) / n_shards;
+    const uint32_t count = counts[shard];
+    const uint32_t shard_base = shard * shard_cap;
+    uint32_t next = 0; // wave-uniform: rays of this wave's share handed out so far
     for (;;) {
+        const unsigned long long idle = __ballot(cur == RT_CUR_DONE);
+        if (!exhausted && __popcll(idle) >= sc.refill_min) {
+            const uint32_t need = (uint32_t)__popcll(idle);
+            const uint32_t base = next;
+            next += need;
+            // i-th ray of this wave's share -> queue index of group (i/64)*W + w, element i%64
+            if ((uint64_t)((next >> 6) * (uint64_t)n_waves + wave_id) * 64u >= count) exhausted = true;
+            if (cur == RT_CUR_DONE) {
+                const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                const uint64_t idx64 = ((uint64_t)(i >> 6) * n_waves + wave_id) * 64u + (i & 63u);
+                const uint32_t idx = shard_base + (uint32_t)idx64;
+                if (idx64 < count) {
+                    const float4 o4 = q_o[idx], d4 = q_d[idx];
+                    r.q = idx;
+                    r.o = V3(o4);
+                    r.d = V3(d4);
+                    r.inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
+                    r.tmax = ANY ? o4.w : INFINITY;
+                    r.t = INFINITY;
+                    r.slot = -1;
+                    sp = 0;
+                    cur = sc.root_ref;
+                }
+            }
+        }
+        if (__ballot(cur != RT_CUR_DONE) == 0ull) break; // nothing fetched: the queue is exhausted
+
+        // ---- one inner-node step (Object.h:322-343)
         if (cur >= 0) {
             const float4* p = sc.pairs + 4 * (size_t)cur;
             const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
             float ld, rd;
-            bool lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), o, inv, ld);
-            bool rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), o, inv, rd);
-            lh = lh && ld < t;
-            rh = rh && rd < t;
+            bool lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
+            bool rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
+            lh = lh && ld < r.t;
+            rh = rh && rd < r.t;
             const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
             if (lh && rh) {
                 const bool left_first = ld < rd; // ties visit the right child first (Object.h:329-336)
@@ -130,53 +197,72 @@ RT_DEV bool traverse(const SceneView& sc, const V3& o, const V3& d, float tmax, 
                 if (sp < RT_SHORT_STACK) lds[sp * RT_BLOCK] = far;
                 else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
                 sp++;
-                continue;
+            } else if (lh) {
+                cur = lref;
+            } else if (rh) {
+                cur = rref;
+            } else if (sp == 0) {
+                cur = RT_CUR_FINISH;
+            } else {
+                sp--;
+                cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
             }
-            if (lh) { cur = lref; continue; }
-            if (rh) { cur = rref; continue; }
-        } else {
-            int slot = ~cur;
-            bool last;
-            do {
-                const float4* tp = sc.tris + 3 * (size_t)slot;
-                const float4 a = tp[0], b = tp[1], c = tp[2];
-                last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
-                // IntersectTriRay2, Object.h:245-264 (edges pre-differenced by the host)
-                const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
-                const V3 h = cross(d, e2);
-                const float det = dot(e1, h);
-                // `a > -1e-7 && a < 1e-7` is written in double in the reference; float(1e-7) is the
-                // smallest float above the double 1e-7, so the fp32 compare accepts the same set.
-                if (!(det > -1e-7f && det < 1e-7f)) {
-                    const float f = 1.f / det;
-                    const V3 s = o - v0;
-                    const float u = f * dot(s, h);
-                    if (!(u < 0.f || u > 1.f)) {
-                        const V3 q = cross(s, e1);
-                        const float v = f * dot(d, q);
-                        if (!(v < 0.f || u + v > 1.f)) {
-                            const float tt = f * dot(e2, q);
-                            // Object.h:260 and 309-315 with tmin = 0
-                            if (tt > 0.0001f && !(tt > tmax) && !(tt < 0.f)) {
-                                tmax = tt;
-                                t = tt;
-                                hit_slot = slot;
-                                hit_t = tt;
-                                hit_u = u;
-                                hit_v = v;
-                                if (ANY) return true;
+        }
+
+        // ---- leaves (Object.h:292-320) and completion: lanes that reached a leaf wait until enough of them have,
+        // so the triangle test runs at a useful lane occupancy (wave-uniform decision)
+        const unsigned long long at_leaf = __ballot(cur < 0 && cur != RT_CUR_DONE);
+        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) continue;
+        if (cur < 0 && cur != RT_CUR_DONE) {
+            if (cur != RT_CUR_FINISH) {
+                int slot = ~cur;
+                bool last;
+                do {
+                    const float4* tp = sc.tris + 3 * (size_t)slot;
+                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
+                    // IntersectTriRay2, Object.h:245-264 (edges pre-differenced by the host)
+                    const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
+                    const V3 h = cross(r.d, e2);
+                    const float det = dot(e1, h);
+                    // `a > -1e-7 && a < 1e-7` is written in double in the reference; float(1e-7) is the
+                    // smallest float above the double 1e-7, so the fp32 compare accepts the same set.
+                    if (!(det > -1e-7f && det < 1e-7f)) {
+                        const float f = 1.f / det;
+                        const V3 s = r.o - v0;
+                        const float u = f * dot(s, h);
+                        if (!(u < 0.f || u > 1.f)) {
+                            const V3 qq = cross(s, e1);
+                            const float v = f * dot(r.d, qq);
+                            if (!(v < 0.f || u + v > 1.f)) {
+                                const float tt = f * dot(e2, qq);
+                                // Object.h:260 and 309-315 with tmin = 0
+                                if (tt > 0.0001f && !(tt > r.tmax) && !(tt < 0.f)) {
+                                    r.tmax = tt;
+                                    r.t = tt;
+                                    r.slot = slot;
+                                    r.u = u;
+                                    r.v = v;
+                                    if (ANY) last = true;
+                                }
                             }
                         }
                     }
+                    slot++;
+                } while (!last);
+                if ((ANY && r.slot >= 0) || sp == 0) {
+                    cur = RT_CUR_FINISH;
+                } else {
+                    sp--;
+                    cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
                 }
-                slot++;
-            } while (!last);
+            }
+            if (cur == RT_CUR_FINISH) {
+                sink(r);
+                cur = RT_CUR_DONE;
+            }
         }
-        if (sp == 0) break;
-        sp--;
-        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
     }
-    return hit_slot >= 0;
 }
 
 // ---------------------------------------------------------------- shading
@@ -193,7 +279,11 @@ RT_DEV V3 refract(const V3& uv, const V3& n, float eta) {                       
     V3 par = (-sqrtf(fabsf(1.0f - len2(perp)))) * n;
     return perp + par;
 }
-RT_DEV float pow5(float x) { return powf(x, 5.f); }
+// pow(x, 5) of the reference (Material.cpp:39,116; Utils.h:100) as a multiply chain (<= 2 ulp from libm's pow)
+RT_DEV float pow5(float x) {
+    const float x2 = x * x;
+    return (x2 * x2) * x;
+}
 RT_DEV float schlick_reflectance(float cosine, float ref_idx) { // Utils.h:96-101
     float r0 = (1.f - ref_idx) / (1.f + ref_idx);
     r0 = r0 * r0;
@@ -210,7 +300,9 @@ RT_DEV V3 cosine_sample(Rng& r) { // Utils.h:70-83
     float phi = 2.f * kPi * r1;
     float ct = sqrtf(1.f - r2);
     float st = sqrtf(r2);
-    return V3(cosf(phi) * st, sinf(phi) * st, ct);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    return V3(cp * st, sp * st, ct);
 }
 
 struct Surf { // Intersection, Def.h:11-40
@@ -226,11 +318,10 @@ struct Scatter {
 RT_DEV float ggx_D(const V3& N, const V3& H, float alpha) {
     float ndh = fmax_sel(dot(H, N), 0.f);
     if (ndh <= 0.f) return 0.f;
-    float half_angle = acosf(ndh);
     float a2 = alpha * alpha;
-    float tn = tanf(half_angle);
-    float inner = a2 + tn * tn;
     float n2 = ndh * ndh;
+    // pow(tan(acos(NdotH)), 2) (Material.cpp:8-10) = (1 - c^2) / c^2, without the two transcendentals
+    float inner = a2 + (1.f - n2) / n2;
     float denom = kPi * (n2 * n2) * (inner * inner);
     if (denom <= 0.f) return 0.f;
     return a2 / denom;
@@ -248,10 +339,14 @@ RT_DEV float beckmann_D(const V3& N, const V3& H, float alpha) {
 RT_DEV V3 microfacet_sample_h(const V3& N, float alpha, bool beckmann, Rng& r) { // Material.cpp:14-30
     float r1 = r.next();
     float r2 = r.next();
-    float theta_m = beckmann ? atanf(sqrtf(-(alpha * alpha) * logf(1.f - r1))) : atanf((alpha * sqrtf(r1)) / sqrtf(1.f - r1));
+    // theta_m = atan(x) (Material.cpp:18); only its sine and cosine are used: cos = 1/sqrt(1+x^2), sin = x cos
+    const float x = beckmann ? sqrtf(-(alpha * alpha) * logf(1.f - r1)) : (alpha * sqrtf(r1)) / sqrtf(1.f - r1);
     float phi = 2.f * kPi * r2;
-    float st = sinf(theta_m);
-    V3 m(cosf(phi) * st, sinf(phi) * st, cosf(theta_m));
+    const float ct = 1.f / sqrtf(1.f + x * x);
+    const float st = x * ct;
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    V3 m(cp * st, sp * st, ct);
     V3 T, B;
     onb(N, T, B);
     return T * m.x + B * m.y + N * m.z;
@@ -310,8 +405,10 @@ RT_DEV V3 sample_vndf(const V3& Wi, float ax, float ay, Rng& r) { // Material.cp
     V3 T2 = cross(T1, Vh);
     float rr = sqrtf(r1);
     float phi = 2.0f * kPi * r2;
-    float t1 = rr * cosf(phi);
-    float t2 = rr * sinf(phi);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    float t1 = rr * cp;
+    float t2 = rr * sp;
     float s = 0.5f * (1.f + Vh.z);
     t2 = (1.f - s) * sqrtf(1.f - t1 * t1) + s * t2;
     V3 Nh = t1 * T1 + t2 * T2 + sqrtf(fmax_sel(1.f - t1 * t1 - t2 * t2, 0.f)) * Vh;
@@ -344,7 +441,9 @@ RT_DEV V3 clearcoat_sample(float ag, Rng& r) { // Material.cpp:267-280
     float phi = 2.f * kPi * r2;
     float ct = sqrtf((1.f - powf(ag2, 1.f - r1)) / (1.f - ag2));
     float st = clampf(sqrtf(1.f - (ct * ct)), 0.f, 1.f);
-    return V3(st * cosf(phi), st * sinf(phi), ct);
+    float sp, cp;
+    sincosf(phi, &sp, &cp);
+    return V3(st * cp, st * sp, ct);
 }
 RT_DEV V3 clearcoat_eval(const V3& V, const V3& L, const V3& H, float gloss, float* pdf) { // Material.cpp:282-294
     float r0 = r0_from_ior(1.5f);
@@ -704,9 +803,8 @@ RT_DEV V3 env_lookup(const SceneView& sc, float u, float v) { // Image.h:46-64
     V3 ff = env_texel(sc, ufi, vfi), fc = env_texel(sc, ufi, vci), cf = env_texel(sc, uci, vfi), cc = env_texel(sc, uci, vci);
     return (ff * (1.f - uo)) * (1.f - vo) + (fc * (1.f - uo)) * (vo) + (cf * (uo)) * (1.f - vo) + (cc * (uo)) * (vo);
 }
-RT_DEV float env_pdf_of(const SceneView& sc, const V3& color, float theta) {
+RT_DEV float env_pdf_of(const SceneView& sc, const V3& color, float st) { // st = sin(theta)
     float pdf = luminance(color) / sc.env_total;
-    float st = sinf(theta);
     if (st == 0.f) return 0.f;
     return pdf * ((float)(sc.env_w * sc.env_h) / (2.f * kPi * kPi * st));
 }
@@ -716,7 +814,7 @@ RT_DEV V3 env_eval(const SceneView& sc, const V3& dir, float* pdf) { // main.cpp
     float u = (kPi + phi) / kPi * 0.5f + sc.env_offset;
     float v = theta / kPi;
     V3 color = env_lookup(sc, u, v);
-    *pdf = env_pdf_of(sc, color, theta);
+    *pdf = env_pdf_of(sc, color, sinf(theta));
     return color;
 }
 RT_DEV V3 env_sample(const SceneView& sc, float rnd, V3* dir, float* pdf) { // main.cpp:121-143,165-184
@@ -741,9 +839,11 @@ RT_DEV V3 env_sample(const SceneView& sc, float rnd, V3* dir, float* pdf) { // m
     ux -= sc.env_offset;
     float phi = ux * 2.f * kPi;
     float theta = uy * kPi;
-    float st = sinf(theta);
-    *dir = V3(-st * cosf(phi), cosf(theta), -st * sinf(phi));
-    *pdf = env_pdf_of(sc, color, theta);
+    float st, ct, sp, cp;
+    sincosf(theta, &st, &ct);
+    sincosf(phi, &sp, &cp);
+    *dir = V3(-st * cp, ct, -st * sp);
+    *pdf = env_pdf_of(sc, color, st);
     return color;
 }
 
@@ -795,8 +895,10 @@ RT_DEV void camera_ray(const rt_camera& cam, int x, int y, uint32_t i, uint32_t 
     float ox, oy;
     if (cam.filter == RT_FILTER_GAUSSIAN) {
         float rad = cam.filter_param * sqrtf(-2.f * logf(fmax_sel(dx, 1e-8f)));
-        ox = rad * cosf(2.f * kPi * dy);
-        oy = rad * sinf(2.f * kPi * dy);
+        float sp, cp;
+        sincosf(2.f * kPi * dy, &sp, &cp);
+        ox = rad * cp;
+        oy = rad * sp;
     } else {
         ox = (2.f * dx - 1.f) * (cam.filter_param * 0.5f);
         oy = (2.f * dy - 1.f) * (cam.filter_param * 0.5f);

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -26,6 +27,8 @@
 using namespace rtd;
 
 #define RT_MAX_LIGHTS 15 // shadow slots per path = env + lights <= 16
+#define RT_SHARDS 16      // sub-queues per queue: one reservation counter each (a single counter saturates at ~88 atomics/us)
+#define RT_COUNTS (128 * RT_SHARDS)
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
@@ -59,7 +62,7 @@ struct Wave {
     // dense shadow-ray queue
     float4* s_o;      // origin.xyz, tmax
     float4* s_d;      // dir.xyz, target index k*cap + q (bits)
-    // counters: [0..depth] live rays entering bounce b, [64..64+depth) shadow rays of bounce b
+    // counters: [b*S + s] live rays of shard s entering bounce b (bounce 0: s = 0 only), [64*S + b*S + s] shadow rays
     uint32_t* counts;
 };
 
@@ -73,6 +76,9 @@ struct PassParams {
     uint32_t seed;
     int32_t cap;
     int32_t K;                // shadow slots per path
+    uint32_t n_shards;        // sub-queues per ray queue (bounce >= 1) and per shadow queue
+    uint32_t shard_cap;       // ray-queue entries reserved per shard (multiple of RT_BLOCK)
+    uint32_t capq;            // n_shards * shard_cap >= cap: range of queue indices
     int32_t has_env;
 };
 
@@ -92,64 +98,94 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
 }
 
 __global__ __launch_bounds__(RT_BLOCK) void k_closest(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                      const uint32_t* __restrict__ count, float4* __restrict__ hit, int want_tri_id) {
+                                                      const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
+                                                      float4* __restrict__ hit, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_BLOCK];
-    const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (q >= *count) return;
-    const float4 o4 = q_o[q], d4 = q_d[q];
-    int slot;
-    float t = INFINITY, u = 0.f, v = 0.f;
-    traverse<false>(sc, V3(o4), V3(d4), INFINITY, stack + threadIdx.x, slot, t, u, v);
-    if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
-    hit[q] = make_float4(__int_as_float(slot), t, u, v);
+    trace_queue<false>(sc, q_o, q_d, counts, n_shards, shard_cap, stack + threadIdx.x, [&](const RayState& r) {
+        int slot = r.slot;
+        if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
+        hit[r.q] = make_float4(__int_as_float(slot), r.t, r.u, r.v);
+    });
 }
 
 // Dense shadow queue -> vis[target] = 1 when nothing blocks the segment.
 __global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
-                                                     const uint32_t* __restrict__ count, uint8_t* __restrict__ vis) {
+                                                     const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
+                                                     uint8_t* __restrict__ vis) {
     __shared__ int stack[RT_SHORT_STACK * RT_BLOCK];
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (j >= *count) return;
-    const float4 o4 = s_o[j], d4 = s_d[j];
-    int slot;
-    float t, u, v;
-    const bool occluded = traverse<true>(sc, V3(o4), V3(d4), o4.w, stack + threadIdx.x, slot, t, u, v);
-    vis[__float_as_uint(d4.w)] = occluded ? 0 : 1;
+    trace_queue<true>(sc, s_o, s_d, counts, n_shards, shard_cap, stack + threadIdx.x,
+                      [&](const RayState& r) { vis[__float_as_uint(s_d[r.q].w)] = r.slot >= 0 ? 0 : 1; });
 }
 
 // Parity hook variant: rays + tmax in, occluded flag out (rt_trace_any).
 __global__ __launch_bounds__(RT_BLOCK) void k_any(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                  uint32_t n, uint8_t* __restrict__ occ) {
+                                                  const uint32_t* __restrict__ count, uint8_t* __restrict__ occ) {
     __shared__ int stack[RT_SHORT_STACK * RT_BLOCK];
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (j >= n) return;
-    const float4 o4 = q_o[j], d4 = q_d[j];
-    int slot;
-    float t, u, v;
-    occ[j] = traverse<true>(sc, V3(o4), V3(d4), o4.w, stack + threadIdx.x, slot, t, u, v) ? 1 : 0;
+    trace_queue<true>(sc, q_o, q_d, count, 1u, 0u, stack + threadIdx.x, [&](const RayState& r) { occ[r.q] = r.slot >= 0 ? 1 : 0; });
 }
 
-// wave64 compaction: every lane with `want` gets a dense index in the queue
-// counted by *counter (one atomic per wave).
-RT_DEV uint32_t wave_reserve(bool want, uint32_t* counter) {
-    const unsigned long long mask = __ballot(want);
+// wave64 compaction over the lanes that call it (under divergence: the lanes of the current branch): ONE atomic per
+// wave reserves, for every calling lane, `per_lane` entries plus one more for lanes with `extra`; returns the calling
+// lane's first entry.  Entries of one lane are contiguous, lanes in lane order.
+RT_DEV uint32_t wave_reserve(uint32_t per_lane, bool extra, uint32_t* counter) {
+    const unsigned long long all = __ballot(true);
+    const unsigned long long ext = __ballot(extra);
     const uint32_t lane = __lane_id();
-    const uint32_t before = __popcll(mask & ((1ull << lane) - 1ull));
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const uint32_t before = per_lane * (uint32_t)__popcll(all & lt) + (uint32_t)__popcll(ext & lt);
+    const uint32_t total = per_lane * (uint32_t)__popcll(all) + (uint32_t)__popcll(ext);
+    const int leader = __ffsll((long long)all) - 1;
     uint32_t base = 0;
-    if (mask != 0ull) {
-        const int leader = __ffsll((long long)mask) - 1;
-        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = __shfl(base, leader);
-    }
+    if ((int)lane == leader && total) base = atomicAdd(counter, total);
+    base = __shfl(base, leader);
     return base + before;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc, Wave w, PassParams pp, int bounce, int last_bounce) {
+// Queue index -> is this entry live?  (uniform per workgroup: shard_cap is a multiple of RT_BLOCK)
+RT_DEV bool queue_entry_live(const Wave& w, const PassParams& pp, int bounce, uint32_t q, bool* block_idle) {
+    const uint32_t n_sh = bounce == 0 ? 1u : pp.n_shards;
+    const uint32_t cap_sh = bounce == 0 ? pp.capq : pp.shard_cap;
+    const uint32_t bq = blockIdx.x * RT_BLOCK;
+    const uint32_t shard = bq / cap_sh;
+    if (shard >= n_sh) {
+        *block_idle = true;
+        return false;
+    }
+    const uint32_t live = w.counts[(uint32_t)bounce * pp.n_shards + shard];
+    const uint32_t local0 = bq - shard * cap_sh;
+    *block_idle = local0 >= live;
+    return q - shard * cap_sh < live;
+}
+
+#define RT_LDS_CDF 2048 // sampling tables up to this many entries are staged in LDS (8 KB + 16 KB per workgroup)
+
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, PassParams pp, int bounce, int last_bounce) {
+    // The two sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox); from LDS a step
+    // costs ~100 cycles instead of an L2 round trip.
+    __shared__ float s_env_cdf[RT_LDS_CDF];
+    __shared__ rt_emissive_tri s_emissive[RT_LDS_CDF];
     const int in = bounce & 1, out = in ^ 1;
     const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (q >= w.counts[bounce]) return;
-    // Everything below runs under divergence; wave_reserve() compacts over the lanes
-    // that reach it, which is all a dense queue needs.
+    bool block_idle;
+    const bool live = queue_entry_live(w, pp, bounce, q, &block_idle);
+    if (block_idle) return; // whole workgroup idle (uniform)
+    SceneView sc = sc_in;
+    {
+        const int n_env = sc_in.env_cdf ? sc_in.env_w * sc_in.env_h : 0;
+        if (n_env > 0 && n_env <= RT_LDS_CDF) {
+            for (int i = threadIdx.x; i < n_env; i += RT_BLOCK) s_env_cdf[i] = sc_in.env_cdf[i];
+            sc.env_cdf = s_env_cdf;
+        }
+        if (sc_in.n_emissive > 0 && sc_in.n_emissive <= RT_LDS_CDF) {
+            for (int i = threadIdx.x; i < sc_in.n_emissive; i += RT_BLOCK) s_emissive[i] = sc_in.emissive[i];
+            sc.emissive = s_emissive;
+        }
+        __syncthreads();
+    }
+    if (!live) return;
+    // Everything below runs under divergence; wave_reserve() compacts over the lanes that reach it, which is all a
+    // dense queue needs.  This workgroup appends to output shard blockIdx.x % n_shards.
+    const uint32_t out_shard = blockIdx.x % pp.n_shards;
     const float4 o4 = w.q_o[in][q], d4 = w.q_d[in][q], h4 = w.hit[q];
     const int p = __float_as_int(o4.w);
     const V3 ro(o4), rd(d4);
@@ -218,28 +254,34 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc, Wave w, PassPa
     // shade_direct_NEE, main.cpp:240-317: contributions are computed here, the visibility
     // tests run in k_shadow over a dense queue, k_nee_resolve applies them in slot order.
     const V3 sh_origin = si.point + si.normal * 0.0001f;
-    uint32_t* shadow_count = &w.counts[64 + bounce];
-    int k = 0;
+    V3 env_dir(0.f), env_c(0.f);
+    bool want_env = false;
     if (pp.has_env) {
         float env_pdf;
-        V3 dir;
-        V3 col = env_sample(sc, rng.next(), &dir, &env_pdf);
-        V3 c(0.f);
-        const bool want = dot(dir, si.normal) > 0.f;
-        if (want) {
+        V3 col = env_sample(sc, rng.next(), &env_dir, &env_pdf);
+        want_env = dot(env_dir, si.normal) > 0.f;
+        if (want_env) {
             float bp;
-            V3 f = mat_eval(mat, si, rd, dir, &bp);
+            V3 f = mat_eval(mat, si, rd, env_dir, &bp);
             float mis = power_heuristic(env_pdf, bp);
-            c = ((mis * f) * col) / env_pdf;
-            const uint32_t j = wave_reserve(true, shadow_count);
-            w.s_o[j] = pack(sh_origin, INFINITY);
-            w.s_d[j] = pack(dir, __uint_as_float(q));
+            env_c = ((mis * f) * col) / env_pdf;
         }
-        w.contrib[q] = pack(c, 0.f);
+        w.contrib[q] = pack(env_c, 0.f);
         w.vis[q] = 0;
+    }
+    // one reservation for all of this wave's shadow rays: [env ray] + one per light, contiguous per lane
+    uint32_t j = out_shard * (uint32_t)pp.K * pp.shard_cap +
+                 wave_reserve((uint32_t)sc.n_lights, want_env, &w.counts[64u * pp.n_shards + (uint32_t)bounce * pp.n_shards + out_shard]);
+    int k = 0;
+    if (pp.has_env) {
+        if (want_env) {
+            w.s_o[j] = pack(sh_origin, INFINITY);
+            w.s_d[j] = pack(env_dir, __uint_as_float(q));
+            j++;
+        }
         k = 1;
     }
-    for (int i = 0; i < sc.n_lights; i++, k++) {
+    for (int i = 0; i < sc.n_lights; i++, k++, j++) {
         const rt_light& L = sc.lights[i];
         V3 point, normal;
         light_sample(sc, L, rng, &point, &normal);
@@ -257,10 +299,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc, Wave w, PassPa
             c = (((mis * f) / lpdf) * 1.f) * mat_emitted(sc.materials[L.material]);
         }
         // the reference traces this ray before it looks at denom (main.cpp:281-295)
-        const size_t target = (size_t)k * pp.cap + q;
-        const uint32_t j = wave_reserve(true, shadow_count);
+        const uint32_t target = (uint32_t)k * pp.capq + q;
         w.s_o[j] = pack(sh_origin, length - 0.001f);
-        w.s_d[j] = pack(ld, __uint_as_float((uint32_t)target));
+        w.s_d[j] = pack(ld, __uint_as_float(target));
         w.contrib[target] = pack(c, 0.f);
         w.vis[target] = 0;
     }
@@ -271,7 +312,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc, Wave w, PassPa
     w.T_pdf[p] = pack(T, scat.pdf);
     w.prev[p] = pack(si.point, __uint_as_float(rng.ctr));
     if (!last_bounce) { // next-bounce ray queue, compacted over the surviving lanes
-        const uint32_t qi = wave_reserve(true, &w.counts[bounce + 1]);
+        const uint32_t qi = out_shard * pp.shard_cap + wave_reserve(1u, false, &w.counts[(uint32_t)(bounce + 1) * pp.n_shards + out_shard]);
         w.q_o[out][qi] = pack(scat.origin, __int_as_float(p));
         w.q_d[out][qi] = pack(scat.dir, 0.f);
     }
@@ -281,12 +322,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc, Wave w, PassPa
 __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp, int bounce) {
     const int in = bounce & 1;
     const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (q >= w.counts[bounce]) return;
+    bool block_idle;
+    if (!queue_entry_live(w, pp, bounce, q, &block_idle)) return;
     const float4 T4 = w.q_T[q];
     if (T4.w == 0.f) return;
     V3 direct(0.f);
     for (int k = 0; k < pp.K; k++)
-        if (w.vis[(size_t)k * pp.cap + q]) direct = direct + V3(w.contrib[(size_t)k * pp.cap + q]);
+        if (w.vis[(size_t)k * pp.capq + q]) direct = direct + V3(w.contrib[(size_t)k * pp.capq + q]);
     const int p = __float_as_int(w.q_o[in][q].w);
     V3 rad(w.rad[p]);
     rad = rad + V3(T4) * direct;
@@ -327,6 +369,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
 // -------------------------------------------------------------- host side
 struct rt_scene {
     int device = 0;
+    unsigned persistent_blocks = 2048; // resident 256-thread workgroups: CUs x 8 (32 waves per CU)
     hipStream_t stream = nullptr;
     SceneView view{};
     int64_t n_pairs = 0, n_tris = 0;
@@ -389,7 +432,7 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K) {
     if ((rc = wave_alloc(s, &w.vis, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_o, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_d, kc))) return rc;
-    if ((rc = wave_alloc(s, &w.counts, (size_t)128))) return rc;
+    if ((rc = wave_alloc(s, &w.counts, (size_t)RT_COUNTS))) return rc;
     s->wave_cap = cap;
     s->wave_K = K;
     return RT_OK;
@@ -452,6 +495,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
 
     rt_scene* s = new rt_scene;
     s->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            s->persistent_blocks = (unsigned)prop.multiProcessorCount * 8u;
+    }
     int rc = RT_OK;
     auto bail = [&](int code) {
         rt_scene_destroy(s);
@@ -481,7 +529,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->view.tris = (const float4*)tris;
     s->view.normals = (const float4*)normals;
     s->view.root_ref = d->root_ref;
+    s->view.refill_min = 16;
+    s->view.leaf_min = 16;
+    if (const char* e = getenv("RT_TUNE_REFILL_MIN")) s->view.refill_min = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_TUNE_LEAF_MIN")) s->view.leaf_min = std::max(1, atoi(e));
     s->view.n_lights = d->n_lights;
+    s->view.n_emissive = d->n_emissive_tris;
     s->n_pairs = d->n_pairs;
     s->n_tris = d->n_tris;
     s->n_materials = d->n_materials;
@@ -542,14 +595,15 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     } while (0)
     TRY(hipMalloc((void**)&d_o, (size_t)n * sizeof(float4)));
     TRY(hipMalloc((void**)&d_d, (size_t)n * sizeof(float4)));
-    TRY(hipMalloc((void**)&d_count, sizeof(uint32_t)));
+    TRY(hipMalloc((void**)&d_count, 2 * sizeof(uint32_t)));
     TRY(hipMemcpyAsync(d_o, o.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     TRY(hipMemcpyAsync(d_d, d.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-    const uint32_t n32 = (uint32_t)n;
-    TRY(hipMemcpyAsync(d_count, &n32, sizeof(n32), hipMemcpyHostToDevice, s->stream));
+    const uint32_t n32[2] = {(uint32_t)n, 0u}; // ray count, fetch cursor
+    TRY(hipMemcpyAsync(d_count, n32, sizeof(n32), hipMemcpyHostToDevice, s->stream));
+    const unsigned grid = std::min(blocks_for(n), s->persistent_blocks);
     if (hits) {
         TRY(hipMalloc((void**)&d_hit, (size_t)n * sizeof(float4)));
-        hipLaunchKernelGGL(k_closest, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_hit, 1);
+        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, 1u, 0u, d_hit, 1);
         TRY(hipGetLastError());
         std::vector<float4> h((size_t)n);
         TRY(hipMemcpyAsync(h.data(), d_hit, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
@@ -564,7 +618,7 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
         }
     } else {
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
-        hipLaunchKernelGGL(k_any, dim3(blocks_for(n)), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, n32, d_occ);
+        hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_occ);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, s->stream));
         TRY(hipStreamSynchronize(s->stream));
@@ -596,11 +650,13 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     if (spp_pass <= 0) spp_pass = (int)std::max<int64_t>(1, (int64_t)(8 << 20) / npix);
     spp_pass = std::min(spp_pass, o->spp_count);
     const int64_t cap = npix * spp_pass;
+    const int64_t shard_cap = ((cap + (int64_t)RT_SHARDS * RT_BLOCK - 1) / ((int64_t)RT_SHARDS * RT_BLOCK)) * RT_BLOCK;
+    const int64_t capq = shard_cap * RT_SHARDS;
     if (cap > (int64_t)1 << 30) return fail(RT_ERR_LIMIT, "rt_render: more than 2^30 paths per pass; lower spp_per_pass");
     const bool has_env = s->view.env_rgb != nullptr;
     const int K = (has_env ? 1 : 0) + s->n_lights;
     int rc;
-    if ((rc = ensure_wave(s, cap, K))) return rc;
+    if ((rc = ensure_wave(s, capq, K))) return rc;
 
     // accumulation target
     const size_t sum_n = (size_t)o->width * o->height * 3;
@@ -638,7 +694,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         if (timing) (void)hipEventRecord(s->ev_pool[ev_next++], s->stream);
     };
 
-    std::vector<uint32_t> h_counts((size_t)n_pass * 128);
+    std::vector<uint32_t> h_counts((size_t)n_pass * RT_COUNTS);
     HIPCHK(hipEventRecord(s->ev_begin, s->stream));
     for (int pass = 0; pass < n_pass; pass++) {
         PassParams pp;
@@ -655,35 +711,43 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         pp.cap = (int32_t)(npix * pp.spp_pass);
         pp.K = K;
         pp.has_env = has_env ? 1 : 0;
-        const unsigned grid = blocks_for(pp.cap);
-        // contrib/vis slot stride must be the capacity of THIS pass
-        HIPCHK(hipMemsetAsync(s->wave.counts, 0, 128 * sizeof(uint32_t), s->stream));
+        // queue geometry is that of the call's largest pass, so NEE slot strides stay valid for a short last pass
+        pp.n_shards = RT_SHARDS;
+        pp.shard_cap = (uint32_t)shard_cap;
+        pp.capq = (uint32_t)capq;
+        const unsigned grid0 = blocks_for(pp.cap);   // bounce-0 queue is dense
+        const unsigned gridq = blocks_for(pp.capq);  // later queues are sharded
+        const unsigned pgrid = s->persistent_blocks; // persistent traversal launches (multiple of RT_SHARDS waves)
+        HIPCHK(hipMemsetAsync(s->wave.counts, 0, RT_COUNTS * sizeof(uint32_t), s->stream));
         mark();
-        hipLaunchKernelGGL(k_generate, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->wave, pp);
+        hipLaunchKernelGGL(k_generate, dim3(grid0), dim3(RT_BLOCK), 0, s->stream, s->wave, pp);
         mark();
         for (int b = 0; b < o->max_depth; b++) {
             const int in = b & 1;
+            uint32_t* ray_counts = s->wave.counts + (size_t)b * RT_SHARDS;
+            uint32_t* shadow_counts = s->wave.counts + (size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS;
             mark();
-            hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave.q_o[in], s->wave.q_d[in],
-                               s->wave.counts + b, s->wave.hit, 0);
+            hipLaunchKernelGGL(k_closest, dim3(b == 0 ? std::min(grid0, pgrid) : pgrid), dim3(RT_BLOCK), 0, s->stream, s->view,
+                               s->wave.q_o[in], s->wave.q_d[in], ray_counts, b == 0 ? 1u : (uint32_t)RT_SHARDS, pp.shard_cap, s->wave.hit, 0);
             mark();
             mark();
-            hipLaunchKernelGGL(k_shade, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave, pp, b, b == o->max_depth - 1 ? 1 : 0);
+            hipLaunchKernelGGL(k_shade, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave, pp, b,
+                               b == o->max_depth - 1 ? 1 : 0);
             mark();
             mark();
             if (K > 0)
-                hipLaunchKernelGGL(k_shadow, dim3(blocks_for((int64_t)pp.cap * K)), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave.s_o,
-                                   s->wave.s_d, s->wave.counts + 64 + b, s->wave.vis);
+                hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave.s_o, s->wave.s_d, shadow_counts,
+                                   (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, s->wave.vis);
             mark();
             mark();
-            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, b);
+            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, b);
             mark();
         }
         mark();
         hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(npix)), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, d_sum);
         mark();
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&h_counts[(size_t)pass * 128], s->wave.counts, 128 * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&h_counts[(size_t)pass * RT_COUNTS], s->wave.counts, RT_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     }
     HIPCHK(hipEventRecord(s->ev_end, s->stream));
     if (!dev_out) HIPCHK(hipMemcpyAsync(radiance_sum, d_sum, sum_n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -692,13 +756,18 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     if (stats) {
         rt_stats st{};
         for (int pass = 0; pass < n_pass; pass++) {
-            const uint32_t* c = &h_counts[(size_t)pass * 128];
+            const uint32_t* c = &h_counts[(size_t)pass * RT_COUNTS];
             st.paths += c[0];
             for (int b = 0; b < o->max_depth; b++) {
-                st.rays_closest += c[b];
-                st.rays_shadow += c[64 + b];
-                if (c[b]) st.launches_closest++;
-                if (c[64 + b]) st.launches_shadow++;
+                uint64_t nc = 0, ns = 0;
+                for (int sh = 0; sh < RT_SHARDS; sh++) {
+                    nc += c[b * RT_SHARDS + sh];
+                    ns += c[64 * RT_SHARDS + b * RT_SHARDS + sh];
+                }
+                st.rays_closest += nc;
+                st.rays_shadow += ns;
+                if (nc) st.launches_closest++;
+                if (ns) st.launches_shadow++;
             }
         }
         HIPCHK(hipEventElapsedTime(&st.ms_total, s->ev_begin, s->ev_end));

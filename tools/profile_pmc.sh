@@ -1,0 +1,16 @@
+#!/bin/bash
+# PMC passes over a short bench run (one 16-spp step at 1080p, 8 bounces). Each pass is its own rocprofv3 run.
+# usage: tools/profile_pmc.sh <outdir>
+set -u
+OUT=${1:-gpurun_out/pmc}
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+run() {
+  name=$1; shift
+  timeout -s KILL 240 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+}
+run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE &&
+run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INSTS_FLAT &&
+run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum &&
+run fetch FETCH_SIZE &&
+run write WRITE_SIZE
