@@ -110,8 +110,30 @@ struct RayState {
     float t;     // best hit so far, INF before the first (Object.h:281)
     float u, v;
     int slot;    // best hit's triangle slot, -1 = none
+    bool exact;  // ray needs the select-form slab test (non-finite 1/dir or origin: NaNs possible)
     uint32_t q;  // queue position of this ray
 };
+
+// Same test with v_min_f32 / v_max3_f32 instead of compare+select chains (8 instructions instead of 20 selects with
+// VCC hazards).  IEEE min/max differ from the reference's select forms only when an operand is NaN (and in the sign of
+// a zero result, which no comparison below can observe); a NaN needs 0 * inf, i.e. an infinite 1/dir.  trace_queue takes
+// this path only while every lane stepping has a finite origin and finite 1/dir, so results are bit-identical.
+RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv, float& tnear_out) {
+    V3 t0 = (bmin - o) * inv;
+    V3 t1 = (bmax - o) * inv;
+    // written as instructions: through fminf/fmaxf hipcc adds a canonicalising v_max_f32 x, x, x per operand
+    float ax, ay, az, bx, by, bz, tnear, tfar;
+    asm("v_min_f32 %0, %1, %2" : "=v"(ax) : "v"(t0.x), "v"(t1.x));
+    asm("v_min_f32 %0, %1, %2" : "=v"(ay) : "v"(t0.y), "v"(t1.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(az) : "v"(t0.z), "v"(t1.z));
+    asm("v_max_f32 %0, %1, %2" : "=v"(bx) : "v"(t0.x), "v"(t1.x));
+    asm("v_max_f32 %0, %1, %2" : "=v"(by) : "v"(t0.y), "v"(t1.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(bz) : "v"(t0.z), "v"(t1.z));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tnear) : "v"(ax), "v"(ay), "v"(az));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tfar) : "v"(bx), "v"(by), "v"(bz));
+    tnear_out = tnear;
+    return !(tnear > tfar || tfar < 0.f);
+}
 
 // Closest-hit (ANY = false: TriangleMesh::intersect, Object.h:273-344) or boolean occlusion (ANY = true:
 // trace_scene as used at main.cpp:250,281) over a dense ray queue, as PERSISTENT wave64s:
@@ -139,6 +161,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
     r.tmax = INFINITY;
     r.u = r.v = 0.f;
     r.o = r.d = r.inv = V3(0.f);
+    r.exact = false;
     int cur = RT_CUR_DONE;
     int sp = 0;
     bool exhausted = false; // wave-uniform
@@ -170,6 +193,11 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                     r.o = V3(o4);
                     r.d = V3(d4);
                     r.inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
+                    {
+                        const float big = fmaxf(fmaxf(fabsf(r.inv.x), fabsf(r.inv.y)), fabsf(r.inv.z));
+                        const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
+                        r.exact = !(big < INFINITY) || !(org < INFINITY); // also true for NaNs
+                    }
                     r.tmax = ANY ? o4.w : INFINITY;
                     r.t = INFINITY;
                     r.slot = -1;
@@ -180,32 +208,41 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
         }
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break; // nothing fetched: the queue is exhausted
 
-        // ---- one inner-node step (Object.h:322-343)
-        if (cur >= 0) {
-            const float4* p = sc.pairs + 4 * (size_t)cur;
-            const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-            float ld, rd;
-            bool lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
-            bool rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
-            lh = lh && ld < r.t;
-            rh = rh && rd < r.t;
-            const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
-            if (lh && rh) {
+        // ---- inner-node steps (Object.h:322-343): two per round, so the wave-level bookkeeping above and below is
+        // paid once per two node visits; written with selects and two short predicated blocks (push / pop)
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            if (cur >= 0) {
+                const float4* p = sc.pairs + 4 * (size_t)cur;
+                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                float ld, rd;
+                bool lh, rh;
+                if (__ballot(r.exact) == 0ull) { // wave-uniform
+                    lh = slab_fast(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
+                    rh = slab_fast(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
+                } else {
+                    lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
+                    rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
+                }
+                lh = lh && ld < r.t;
+                rh = rh && rd < r.t;
+                const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                 const bool left_first = ld < rd; // ties visit the right child first (Object.h:329-336)
-                const int far = left_first ? rref : lref;
-                cur = left_first ? lref : rref;
-                if (sp < RT_SHORT_STACK) lds[sp * RT_BLOCK] = far;
-                else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
-                sp++;
-            } else if (lh) {
-                cur = lref;
-            } else if (rh) {
-                cur = rref;
-            } else if (sp == 0) {
-                cur = RT_CUR_FINISH;
-            } else {
-                sp--;
-                cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
+                // next node when at least one child is hit: the nearer of two, else the one that is hit
+                cur = (lh && (!rh || left_first)) ? lref : rref;
+                if (lh && rh) { // push the farther child
+                    const int far = left_first ? rref : lref;
+                    if (sp < RT_SHORT_STACK) lds[sp * RT_BLOCK] = far;
+                    else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
+                    sp++;
+                } else if (!lh && !rh) { // pop, or finish on an empty stack
+                    if (sp == 0) {
+                        cur = RT_CUR_FINISH;
+                    } else {
+                        sp--;
+                        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
+                    }
+                }
             }
         }
 

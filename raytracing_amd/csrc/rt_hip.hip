@@ -27,7 +27,7 @@
 using namespace rtd;
 
 #define RT_MAX_LIGHTS 15 // shadow slots per path = env + lights <= 16
-#define RT_SHARDS 16      // sub-queues per queue: one reservation counter each (a single counter saturates at ~88 atomics/us)
+#define RT_SHARDS 64      // sub-queues per queue: one reservation counter each (a single counter saturates at ~88 atomics/us)
 #define RT_COUNTS (128 * RT_SHARDS)
 
 // ------------------------------------------------------------------ errors
@@ -165,9 +165,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
     __shared__ float s_env_cdf[RT_LDS_CDF];
     __shared__ rt_emissive_tri s_emissive[RT_LDS_CDF];
     const int in = bounce & 1, out = in ^ 1;
-    const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
     bool block_idle;
-    const bool live = queue_entry_live(w, pp, bounce, q, &block_idle);
+    const bool live = queue_entry_live(w, pp, bounce, blockIdx.x * RT_BLOCK + threadIdx.x, &block_idle);
     if (block_idle) return; // whole workgroup idle (uniform)
     SceneView sc = sc_in;
     {
@@ -182,6 +181,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
         }
         __syncthreads();
     }
+    const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (!live) return;
     // Everything below runs under divergence; wave_reserve() compacts over the lanes that reach it, which is all a
     // dense queue needs.  This workgroup appends to output shard blockIdx.x % n_shards.
@@ -529,7 +529,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->view.tris = (const float4*)tris;
     s->view.normals = (const float4*)normals;
     s->view.root_ref = d->root_ref;
-    s->view.refill_min = 16;
+    s->view.refill_min = 24;
     s->view.leaf_min = 16;
     if (const char* e = getenv("RT_TUNE_REFILL_MIN")) s->view.refill_min = std::max(1, atoi(e));
     if (const char* e = getenv("RT_TUNE_LEAF_MIN")) s->view.leaf_min = std::max(1, atoi(e));
