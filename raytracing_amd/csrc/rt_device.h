@@ -13,8 +13,20 @@
 
 #include "../../include/rt_hip.h"
 
-#define RT_BLOCK 256        // threads per workgroup = 4 wave64
-#define RT_SHORT_STACK 16   // traversal stack entries per lane kept in LDS
+#define RT_BLOCK 256        // threads per workgroup = 4 wave64 (shading / streaming kernels)
+#ifndef RT_TRAV_BLOCK
+#define RT_TRAV_BLOCK 256
+#endif
+#ifndef RT_TOP_PAIRS
+#define RT_TOP_PAIRS 64
+#endif
+// RT_TRAV_BLOCK: threads per workgroup of the traversal kernels (measured: 256 beats 512 and 1024)
+// RT_TOP_PAIRS: child-pair records [0, RT_TOP_PAIRS) are read from LDS (4 KB per workgroup; measured: 64 beats 0 and 256);
+// the host numbers the top levels of the tree first
+#ifndef RT_SHORT_STACK
+#define RT_SHORT_STACK 12
+#endif
+// RT_SHORT_STACK: traversal stack entries per lane kept in LDS (12 KB per 256-thread workgroup)
 #define RT_STACK_TOTAL 64   // reference stack capacity (Object.h:275)
 
 #define RT_DEV __device__ __forceinline__
@@ -81,6 +93,7 @@ struct SceneView {
     const float* env_rgb;
     const float* env_cdf;
     int32_t root_ref;
+    int32_t n_pairs;
     int32_t n_lights;
     int32_t n_emissive;
     int32_t env_w, env_h;
@@ -143,7 +156,7 @@ RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv
 //     which measured slower than no refill at all) and refills of whole groups stay coalesced;
 //   * "while-while" order: all lanes walk inner nodes until none has one pending, then all pending leaves are
 //     tested together — the two bodies are not interleaved per step under partial masks;
-//   * the traversal stack keeps its first RT_SHORT_STACK entries in LDS (column lds[entry * RT_BLOCK]: lanes of a
+//   * the traversal stack keeps its first RT_SHORT_STACK entries in LDS (column lds[entry * RT_TRAV_BLOCK]: lanes of a
 //     wave hit consecutive banks) and spills deeper entries to private memory, up to the reference's 64.
 // Per ray the visit order, the culling rule (`dist < t` at push time, not re-tested at pop), right-child-first on
 // ties and accept-on-equal-t are exactly the reference's, so results do not depend on how rays share a wave.
@@ -151,7 +164,8 @@ RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv
 // fetching once its next group starts past `count` and leaves the loop when its last lane finishes.
 template <bool ANY, class Sink>
 RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                        const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap, int* lds, Sink sink) {
+                        const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap, int* lds,
+                        const float4* top, int n_top, Sink sink) {
     int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
     const uint32_t lane = __lane_id();
     RayState r;
@@ -168,10 +182,10 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
     // The queue is n_shards dense sub-queues (shard s = entries [s*shard_cap, s*shard_cap + counts[s])): the shade
     // kernel fills them through n_shards counters so that no single address takes every reservation atomic.
     // Wave g works on shard g % n_shards; the launch has a multiple of n_shards waves.
-    const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RT_BLOCK / 64) + threadIdx.x / 64));
+    const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RT_TRAV_BLOCK / 64) + threadIdx.x / 64));
     const uint32_t shard = gwave % n_shards;
     const uint32_t wave_id = gwave / n_shards;
-    const uint32_t n_waves = (gridDim.x * (RT_BLOCK / 64)) / n_shards;
+    const uint32_t n_waves = (gridDim.x * (RT_TRAV_BLOCK / 64)) / n_shards;
     const uint32_t count = counts[shard];
     const uint32_t shard_base = shard * shard_cap;
     uint32_t next = 0; // wave-uniform: rays of this wave's share handed out so far
@@ -213,8 +227,16 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
             if (cur >= 0) {
-                const float4* p = sc.pairs + 4 * (size_t)cur;
-                const float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                // the top of the tree (every ray walks it) comes from LDS, which has its own bandwidth beside the
+                // vector L1 that the divergent 64-byte record reads below saturate
+                float4 q0, q1, q2, q3;
+                if (cur < n_top) {
+                    const float4* p = top + 4 * cur;
+                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+                } else {
+                    const float4* p = sc.pairs + 4 * (size_t)cur;
+                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+                }
                 float ld, rd;
                 bool lh, rh;
                 if (__ballot(r.exact) == 0ull) { // wave-uniform
@@ -232,7 +254,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 cur = (lh && (!rh || left_first)) ? lref : rref;
                 if (lh && rh) { // push the farther child
                     const int far = left_first ? rref : lref;
-                    if (sp < RT_SHORT_STACK) lds[sp * RT_BLOCK] = far;
+                    if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = far;
                     else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
                     sp++;
                 } else if (!lh && !rh) { // pop, or finish on an empty stack
@@ -240,7 +262,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                         cur = RT_CUR_FINISH;
                     } else {
                         sp--;
-                        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
+                        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
                     }
                 }
             }
@@ -291,7 +313,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                     cur = RT_CUR_FINISH;
                 } else {
                     sp--;
-                    cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_BLOCK] : spill[sp - RT_SHORT_STACK];
+                    cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
                 }
             }
             if (cur == RT_CUR_FINISH) {

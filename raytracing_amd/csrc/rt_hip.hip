@@ -97,11 +97,21 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     if (p == 0) w.counts[0] = (uint32_t)pp.cap;
 }
 
-__global__ __launch_bounds__(RT_BLOCK) void k_closest(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+// Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup) and returns how many there are.
+RT_DEV int stage_tree_top(const SceneView& sc, float4* s_top) {
+    const int n_top = sc.n_pairs < RT_TOP_PAIRS ? sc.n_pairs : RT_TOP_PAIRS;
+    for (int i = threadIdx.x; i < 4 * n_top; i += RT_TRAV_BLOCK) s_top[i] = sc.pairs[i];
+    __syncthreads();
+    return n_top;
+}
+
+__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                       const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
                                                       float4* __restrict__ hit, int want_tri_id) {
-    __shared__ int stack[RT_SHORT_STACK * RT_BLOCK];
-    trace_queue<false>(sc, q_o, q_d, counts, n_shards, shard_cap, stack + threadIdx.x, [&](const RayState& r) {
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
+    const int n_top = stage_tree_top(sc, s_top);
+    trace_queue<false>(sc, q_o, q_d, counts, n_shards, shard_cap, stack + threadIdx.x, s_top, n_top, [&](const RayState& r) {
         int slot = r.slot;
         if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
         hit[r.q] = make_float4(__int_as_float(slot), r.t, r.u, r.v);
@@ -109,19 +119,23 @@ __global__ __launch_bounds__(RT_BLOCK) void k_closest(SceneView sc, const float4
 }
 
 // Dense shadow queue -> vis[target] = 1 when nothing blocks the segment.
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
+__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
                                                      const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
                                                      uint8_t* __restrict__ vis) {
-    __shared__ int stack[RT_SHORT_STACK * RT_BLOCK];
-    trace_queue<true>(sc, s_o, s_d, counts, n_shards, shard_cap, stack + threadIdx.x,
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
+    const int n_top = stage_tree_top(sc, s_top);
+    trace_queue<true>(sc, s_o, s_d, counts, n_shards, shard_cap, stack + threadIdx.x, s_top, n_top,
                       [&](const RayState& r) { vis[__float_as_uint(s_d[r.q].w)] = r.slot >= 0 ? 0 : 1; });
 }
 
 // Parity hook variant: rays + tmax in, occluded flag out (rt_trace_any).
-__global__ __launch_bounds__(RT_BLOCK) void k_any(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                   const uint32_t* __restrict__ count, uint8_t* __restrict__ occ) {
-    __shared__ int stack[RT_SHORT_STACK * RT_BLOCK];
-    trace_queue<true>(sc, q_o, q_d, count, 1u, 0u, stack + threadIdx.x, [&](const RayState& r) { occ[r.q] = r.slot >= 0 ? 1 : 0; });
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
+    const int n_top = stage_tree_top(sc, s_top);
+    trace_queue<true>(sc, q_o, q_d, count, 1u, 0u, stack + threadIdx.x, s_top, n_top, [&](const RayState& r) { occ[r.q] = r.slot >= 0 ? 1 : 0; });
 }
 
 // wave64 compaction over the lanes that call it (under divergence: the lanes of the current branch): ONE atomic per
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
 // -------------------------------------------------------------- host side
 struct rt_scene {
     int device = 0;
-    unsigned persistent_blocks = 2048; // resident 256-thread workgroups: CUs x 8 (32 waves per CU)
+    unsigned persistent_blocks = 512; // resident 1024-thread traversal workgroups: CUs x 2 (32 waves per CU)
     hipStream_t stream = nullptr;
     SceneView view{};
     int64_t n_pairs = 0, n_tris = 0;
@@ -498,7 +512,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            s->persistent_blocks = (unsigned)prop.multiProcessorCount * 8u;
+            s->persistent_blocks = std::max(4u, ((unsigned)prop.multiProcessorCount * (2048u / RT_TRAV_BLOCK)) / 4u * 4u); // waves % RT_SHARDS == 0
     }
     int rc = RT_OK;
     auto bail = [&](int code) {
@@ -535,6 +549,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (const char* e = getenv("RT_TUNE_LEAF_MIN")) s->view.leaf_min = std::max(1, atoi(e));
     s->view.n_lights = d->n_lights;
     s->view.n_emissive = d->n_emissive_tris;
+    s->view.n_pairs = (int32_t)std::min<int64_t>(d->n_pairs, 0x7fffffff);
     s->n_pairs = d->n_pairs;
     s->n_tris = d->n_tris;
     s->n_materials = d->n_materials;
@@ -600,10 +615,10 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     TRY(hipMemcpyAsync(d_d, d.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     const uint32_t n32[2] = {(uint32_t)n, 0u}; // ray count, fetch cursor
     TRY(hipMemcpyAsync(d_count, n32, sizeof(n32), hipMemcpyHostToDevice, s->stream));
-    const unsigned grid = std::min(blocks_for(n), s->persistent_blocks);
+    const unsigned grid = std::min((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK), s->persistent_blocks);
     if (hits) {
         TRY(hipMalloc((void**)&d_hit, (size_t)n * sizeof(float4)));
-        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, 1u, 0u, d_hit, 1);
+        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, 1u, 0u, d_hit, 1);
         TRY(hipGetLastError());
         std::vector<float4> h((size_t)n);
         TRY(hipMemcpyAsync(h.data(), d_hit, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
@@ -618,7 +633,7 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
         }
     } else {
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
-        hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_occ);
+        hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_occ);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, s->stream));
         TRY(hipStreamSynchronize(s->stream));
@@ -727,7 +742,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
             uint32_t* ray_counts = s->wave.counts + (size_t)b * RT_SHARDS;
             uint32_t* shadow_counts = s->wave.counts + (size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS;
             mark();
-            hipLaunchKernelGGL(k_closest, dim3(b == 0 ? std::min(grid0, pgrid) : pgrid), dim3(RT_BLOCK), 0, s->stream, s->view,
+            hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view,
                                s->wave.q_o[in], s->wave.q_d[in], ray_counts, b == 0 ? 1u : (uint32_t)RT_SHARDS, pp.shard_cap, s->wave.hit, 0);
             mark();
             mark();
@@ -736,7 +751,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
             mark();
             mark();
             if (K > 0)
-                hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave.s_o, s->wave.s_d, shadow_counts,
+                hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, s->wave.s_o, s->wave.s_d, shadow_counts,
                                    (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, s->wave.vis);
             mark();
             mark();

@@ -287,11 +287,22 @@ void Scene::flatten() {
         put3(nn.n2, c.normal);
     }
 
-    // ---- child-pair records, numbered in pre-order of the branch nodes
+    // ---- child-pair records.  Numbering: the first kTopPairs branch nodes in breadth-first order (the top levels,
+    // which the traversal kernels keep in LDS), then the rest in pre-order (a subtree stays close in memory).
+    // Numbering is layout only: visit order and arithmetic are those of the reference's node graph.
+    constexpr int kTopPairs = 256;
     std::vector<int> pair_of(bvh.nodes.size(), -1);
     {
-        std::vector<int> stack{0};
         int next = 0;
+        std::vector<int> level{0};
+        for (size_t head = 0; head < level.size() && next < kTopPairs; head++) {
+            const BVHNode& nd = bvh.nodes[level[head]];
+            if (nd.count != BVH_BRANCH) continue;
+            pair_of[level[head]] = next++;
+            level.push_back(nd.left_node);
+            level.push_back(nd.left_node + 1);
+        }
+        std::vector<int> stack{0};
         while (!stack.empty()) {
             int n = stack.back();
             stack.pop_back();
@@ -300,7 +311,7 @@ void Scene::flatten() {
                 f.tris[nd.left_node + nd.count - 1].tri_id |= RT_TRI_LEAF_END;
                 continue;
             }
-            pair_of[n] = next++;
+            if (pair_of[n] < 0) pair_of[n] = next++;
             stack.push_back(nd.left_node + 1);
             stack.push_back(nd.left_node);
         }
