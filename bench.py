@@ -22,6 +22,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 16
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 VISITS_JSON = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
+# rocprofv3 --pmc passes over `bench.py --steps 1` (tools/profile_pmc.sh + tools/summarize_pmc.py), FETCH_SIZE doubled as
+# MI355X_MICROARCH.md prescribes for gfx950; roofline.traffic = HBM bytes per launch of the dominant kernel from it
+PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary_v2.json")
 
 
 def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
@@ -168,9 +171,14 @@ def main():
             ms = stats["ms_closest"] if kern == "k_closest" else stats["ms_shadow"]
             launches = stats["launches_closest"] if kern == "k_closest" else stats["launches_shadow"]
             gbps = n_rays * v["bytes_per_ray"] / (ms * 1e-3) / 1e9
+            traffic = None
+            if os.path.exists(PMC_JSON):
+                pmc = json.load(open(PMC_JSON)).get(kern, {})
+                if pmc.get("dispatches") and "hbm_read_bytes_corrected" in pmc and "hbm_write_bytes" in pmc:
+                    traffic = (pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]) / pmc["dispatches"]
             out["roofline"] = {
                 "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                "traffic": None, "kernel": kern, "bytes_per_ray": v["bytes_per_ray"], "rays_per_launch": n_rays / max(launches, 1),
+                "traffic": traffic, "algorithmic_bytes_per_launch": n_rays * v["bytes_per_ray"] / max(launches, 1), "kernel": kern, "bytes_per_ray": v["bytes_per_ray"], "rays_per_launch": n_rays / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1), "launches": launches,
             }
         out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
