@@ -29,6 +29,10 @@
 // RT_SHORT_STACK: traversal stack entries per lane kept in LDS (12 KB per 256-thread workgroup)
 #define RT_STACK_TOTAL 64   // reference stack capacity (Object.h:275)
 
+// Queue counters and fetch cursors take atomics from every CU: each sits in its own 128-byte line (counter i at word
+// i * RT_CSTRIDE), because atomics on one line are serviced one after the other wherever in the line they land.
+#define RT_CSTRIDE 32
+
 #define RT_DEV __device__ __forceinline__
 
 namespace rtd {
@@ -88,6 +92,7 @@ struct SceneView {
     const float4* tris;    // 3 x float4 per rt_tri
     const float4* normals; // 3 x float4 per rt_tri_normals
     const rt_material* materials;
+    const uint8_t* tri_type; // material type of each triangle slot (k_classify's sort key)
     const rt_light* lights;
     const rt_emissive_tri* emissive;
     const float* env_rgb;
@@ -100,6 +105,10 @@ struct SceneView {
     float env_total, env_offset;
     int32_t refill_min; // refill a wave's idle lanes once this many are idle
     int32_t leaf_min;   // test pending leaves once this many lanes wait at one (or no lane has an inner node)
+    int32_t pend_min;   // occlusion walk: test pending leaves once this many lanes hold one
+    int32_t pend_full;  // ... or once one lane holds this many (<= RT_PEND_FULL_MAX)
+    int32_t wave_min_rays; // a shard of n rays is worked on by at most ceil(n / wave_min_rays) waves
+    int32_t fetch_chunk;   // rays a wave takes from its shard per cursor atomic (multiple of 64)
 };
 
 // Bounds::intersect, Math.h:755-770
@@ -148,6 +157,68 @@ RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv
     return !(tnear > tfar || tfar < 0.f);
 }
 
+// Ray hand-out of the persistent traversal waves.  A queue is n_shards dense sub-queues (shard s = entries
+// [s*shard_cap, s*shard_cap + counts[s])) and every shard has its own fetch cursor; wave g works on shard g % n_shards
+// (the launch has a multiple of n_shards waves).  A wave with idle lanes takes the next `need` rays of its shard with
+// ONE atomic, so rays of a shard go to whichever of its waves has room: no wave is left holding a long static share
+// while others have finished.  One cursor for the whole queue would saturate (~88 same-address atomics/us on MI355X);
+// 64 shards keep every address far below that.  Rays handed to one wave are consecutive: the fetch is coalesced.
+#ifdef RT_STATS // lane-occupancy instrumentation of the traversal loops (debug builds only: tools/lane_stats.sh)
+__device__ unsigned long long g_rt_stats[16];
+#define RT_STAT_DECL unsigned st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_STAT(i, pred) do { const unsigned long long m_ = __ballot(pred); if (m_) { st_[2 * (i)] += 1; st_[2 * (i) + 1] += (unsigned)__popcll(m_); } } while (0)
+#define RT_STAT_FLUSH(base) do { if (__lane_id() == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_rt_stats[(base) + k_], (unsigned long long)st_[k_]); } while (0)
+#else
+#define RT_STAT_DECL
+#define RT_STAT(i, pred)
+#define RT_STAT_FLUSH(base)
+#endif
+
+struct QueueShare {
+    uint32_t base;     // first queue index of the shard
+    uint32_t count;    // live rays in the shard
+    uint32_t* cursor;  // rays of the shard handed out so far, in chunks
+    uint32_t next, end; // this wave's current chunk: rays [next, end) of the shard are its to hand to its lanes
+    uint32_t chunk;    // rays per cursor atomic (a multiple of 64): a returning atomic costs 1-3 us under load
+    bool exhausted;    // wave-uniform: the cursor has passed count
+};
+RT_DEV QueueShare queue_open(const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
+                             int wave_min_rays, int fetch_chunk) {
+    const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RT_TRAV_BLOCK / 64) + threadIdx.x / 64));
+    const uint32_t shard = gwave % n_shards;
+    QueueShare qs;
+    qs.base = shard * shard_cap;
+    qs.count = counts[(size_t)shard * RT_CSTRIDE];
+    qs.cursor = cursors + (size_t)shard * RT_CSTRIDE;
+    qs.next = qs.end = 0;
+    qs.chunk = (uint32_t)fetch_chunk;
+    // short queues are left to the first waves of each shard: a wave that would get only a few rays costs more in its
+    // drain (lanes idling while its last rays finish) than it adds in parallelism
+    qs.exhausted = (uint64_t)(gwave / n_shards) * (uint64_t)wave_min_rays >= qs.count;
+    return qs;
+}
+RT_DEV bool queue_has_more(const QueueShare& qs) { return qs.next < qs.end || !qs.exhausted; }
+// All lanes call; lanes with `want` get the queue index of a fresh ray (true) or nothing (false: their turn comes with
+// the wave's next chunk).
+RT_DEV bool queue_fetch(QueueShare& qs, bool want, uint32_t* idx) {
+    const unsigned long long idle = __ballot(want);
+    const uint32_t need = (uint32_t)__popcll(idle);
+    const uint32_t lane = __lane_id();
+    if (qs.next == qs.end) { // wave-uniform
+        uint32_t first = 0;
+        if (lane == 0) first = atomicAdd(qs.cursor, qs.chunk);
+        first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        qs.next = first < qs.count ? first : qs.count;
+        qs.end = first + qs.chunk < qs.count ? first + qs.chunk : qs.count;
+        if (first + qs.chunk >= qs.count) qs.exhausted = true;
+    }
+    const uint32_t i = qs.next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+    const bool got = want && i < qs.end;
+    qs.next = qs.next + need < qs.end ? qs.next + need : qs.end;
+    *idx = qs.base + i;
+    return got;
+}
+
 // Closest-hit (ANY = false: TriangleMesh::intersect, Object.h:273-344) or boolean occlusion (ANY = true:
 // trace_scene as used at main.cpp:250,281) over a dense ray queue, as PERSISTENT wave64s:
 //   * every wave refills its idle lanes from its own share of the queue, so lanes whose ray ended early do not idle
@@ -164,8 +235,8 @@ RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv
 // fetching once its next group starts past `count` and leaves the loop when its last lane finishes.
 template <bool ANY, class Sink>
 RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                        const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap, int* lds,
-                        const float4* top, int n_top, Sink sink) {
+                        const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
+                        int* lds, const float4* top, int n_top, Sink sink) {
     int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
     const uint32_t lane = __lane_id();
     RayState r;
@@ -178,54 +249,39 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
     r.exact = false;
     int cur = RT_CUR_DONE;
     int sp = 0;
-    bool exhausted = false; // wave-uniform
-    // The queue is n_shards dense sub-queues (shard s = entries [s*shard_cap, s*shard_cap + counts[s])): the shade
-    // kernel fills them through n_shards counters so that no single address takes every reservation atomic.
-    // Wave g works on shard g % n_shards; the launch has a multiple of n_shards waves.
-    const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RT_TRAV_BLOCK / 64) + threadIdx.x / 64));
-    const uint32_t shard = gwave % n_shards;
-    const uint32_t wave_id = gwave / n_shards;
-    const uint32_t n_waves = (gridDim.x * (RT_TRAV_BLOCK / 64)) / n_shards;
-    const uint32_t count = counts[shard];
-    const uint32_t shard_base = shard * shard_cap;
-    uint32_t next = 0; // wave-uniform: rays of this wave's share handed out so far
+    bool wave_exact = false; // wave-uniform: some lane holds a ray that needs the select-form slab test
+    RT_STAT_DECL
+    QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
-        const unsigned long long idle = __ballot(cur == RT_CUR_DONE);
-        if (!exhausted && __popcll(idle) >= sc.refill_min) {
-            const uint32_t need = (uint32_t)__popcll(idle);
-            const uint32_t base = next;
-            next += need;
-            // i-th ray of this wave's share -> queue index of group (i/64)*W + w, element i%64
-            if ((uint64_t)((next >> 6) * (uint64_t)n_waves + wave_id) * 64u >= count) exhausted = true;
-            if (cur == RT_CUR_DONE) {
-                const uint32_t i = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
-                const uint64_t idx64 = ((uint64_t)(i >> 6) * n_waves + wave_id) * 64u + (i & 63u);
-                const uint32_t idx = shard_base + (uint32_t)idx64;
-                if (idx64 < count) {
-                    const float4 o4 = q_o[idx], d4 = q_d[idx];
-                    r.q = idx;
-                    r.o = V3(o4);
-                    r.d = V3(d4);
-                    r.inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
-                    {
-                        const float big = fmaxf(fmaxf(fabsf(r.inv.x), fabsf(r.inv.y)), fabsf(r.inv.z));
-                        const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
-                        r.exact = !(big < INFINITY) || !(org < INFINITY); // also true for NaNs
-                    }
-                    r.tmax = ANY ? o4.w : INFINITY;
-                    r.t = INFINITY;
-                    r.slot = -1;
-                    sp = 0;
-                    cur = sc.root_ref;
+        if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
+            uint32_t idx;
+            if (queue_fetch(qs, cur == RT_CUR_DONE, &idx)) {
+                const float4 o4 = q_o[idx], d4 = q_d[idx];
+                r.q = idx;
+                r.o = V3(o4);
+                r.d = V3(d4);
+                r.inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
+                {
+                    const float big = fmaxf(fmaxf(fabsf(r.inv.x), fabsf(r.inv.y)), fabsf(r.inv.z));
+                    const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
+                    r.exact = !(big < INFINITY) || !(org < INFINITY); // also true for NaNs
                 }
+                r.tmax = ANY ? o4.w : INFINITY;
+                r.t = INFINITY;
+                r.slot = -1;
+                sp = 0;
+                cur = sc.root_ref;
             }
+            wave_exact = __ballot(r.exact && cur != RT_CUR_DONE) != 0ull;
         }
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break; // nothing fetched: the queue is exhausted
+        RT_STAT(3, cur != RT_CUR_DONE); // rounds, lanes holding a ray
 
         // ---- inner-node steps (Object.h:322-343): two per round, so the wave-level bookkeeping above and below is
         // paid once per two node visits; written with selects and two short predicated blocks (push / pop)
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
+            RT_STAT(0, cur >= 0); // inner steps
             if (cur >= 0) {
                 // the top of the tree (every ray walks it) comes from LDS, which has its own bandwidth beside the
                 // vector L1 that the divergent 64-byte record reads below saturate
@@ -239,7 +295,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 }
                 float ld, rd;
                 bool lh, rh;
-                if (__ballot(r.exact) == 0ull) { // wave-uniform
+                if (!wave_exact) {
                     lh = slab_fast(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
                     rh = slab_fast(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
                 } else {
@@ -276,6 +332,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
             if (cur != RT_CUR_FINISH) {
                 int slot = ~cur;
                 bool last;
+                RT_STAT(1, true); // leaf turns
                 do {
                     const float4* tp = sc.tris + 3 * (size_t)slot;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
@@ -322,6 +379,163 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
             }
         }
     }
+    RT_STAT_FLUSH(0);
+}
+
+#define RT_CUR_HIT ((int)0x80000002)    // occlusion_queue: an occluder was found
+#define RT_PEND_CAP 8      // pending-leaf ring per lane in LDS (occlusion_queue); a power of two
+#define RT_PEND_FULL_MAX 5 // a round of two inner steps adds at most 4 entries, so it must start with <= 4
+
+// Boolean occlusion (trace_scene as used at main.cpp:250,281) over a dense ray queue.  The answer of the reference's
+// any-hit walk does not depend on the order of its steps: its `t` stays infinite until the first accepted triangle
+// ends the walk, so a leaf is reached exactly when the box tests of all its ancestors pass, and the ray is occluded
+// exactly when some reached leaf holds a triangle that passes IntersectTriRay2 with 1e-4 < t <= tmax.  This walk
+// therefore evaluates the same tests on the same nodes but never lets a lane wait at a leaf: a child that is a leaf
+// and whose box is hit goes to a short per-lane pending list (LDS) and the lane carries on with inner nodes; the
+// pending triangles are tested together, oldest (nearest) first and one per lane and turn, once enough lanes hold one
+// (pend_min), a lane holds pend_full of them, or no lane has an inner node left.  Persistent waves, per-shard fetch
+// cursors and LDS/private stack as in trace_queue.  sink(queue index, occluded) is called once per ray.
+template <class Sink>
+RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
+                            int* lds, int* pend, const float4* top, int n_top, Sink sink) {
+    int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
+    const uint32_t lane = __lane_id();
+    V3 o(0.f), d(0.f), inv(0.f);
+    float tmax = 0.f;
+    uint32_t q = 0;
+    bool exact = false;
+    bool wave_exact = false; // wave-uniform: some lane fetched a ray that needs the select-form slab test
+    int cur = RT_CUR_DONE;
+    int sp = 0, np = 0, ph = 0; // stack depth; pending-leaf ring: count and head
+    RT_STAT_DECL
+    QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
+    for (;;) {
+        if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
+            uint32_t idx;
+            if (queue_fetch(qs, cur == RT_CUR_DONE, &idx)) {
+                const float4 o4 = q_o[idx], d4 = q_d[idx];
+                q = idx;
+                o = V3(o4);
+                d = V3(d4);
+                inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
+                const float big = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
+                const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
+                exact = !(big < INFINITY) || !(org < INFINITY);
+                tmax = o4.w;
+                sp = 0;
+                if (sc.root_ref >= 0) {
+                    cur = sc.root_ref;
+                    np = 0;
+                } else { // the whole mesh is one leaf; the root is never box-tested (Object.h:283-290)
+                    pend[(ph & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK] = sc.root_ref;
+                    np = 1;
+                    cur = RT_CUR_FINISH;
+                }
+            }
+            wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
+        }
+        if (__ballot(cur != RT_CUR_DONE) == 0ull) break;
+        RT_STAT(3, cur != RT_CUR_DONE);
+
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            RT_STAT(0, cur >= 0);
+            if (cur >= 0) {
+                float4 q0, q1, q2, q3;
+                if (cur < n_top) {
+                    const float4* p = top + 4 * cur;
+                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+                } else {
+                    const float4* p = sc.pairs + 4 * (size_t)cur;
+                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
+                }
+                float ld, rd;
+                bool lh, rh;
+                if (!wave_exact) {
+                    lh = slab_fast(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), o, inv, ld);
+                    rh = slab_fast(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), o, inv, rd);
+                } else {
+                    lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), o, inv, ld);
+                    rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), o, inv, rd);
+                }
+                lh = lh && ld < INFINITY; // `dist < t` of Object.h:325-326 with t still infinite
+                rh = rh && rd < INFINITY;
+                const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
+                if (lh && lref < 0) {
+                    pend[((ph + np) & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK] = lref;
+                    np++;
+                }
+                if (rh && rref < 0) {
+                    pend[((ph + np) & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK] = rref;
+                    np++;
+                }
+                const bool li = lh && lref >= 0, ri = rh && rref >= 0;
+                const bool left_first = ld < rd;
+                cur = (li && (!ri || left_first)) ? lref : rref;
+                if (li && ri) {
+                    const int far = left_first ? rref : lref;
+                    if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = far;
+                    else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
+                    sp++;
+                } else if (!li && !ri) {
+                    if (sp == 0) {
+                        cur = RT_CUR_FINISH;
+                    } else {
+                        sp--;
+                        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
+                    }
+                }
+            }
+        }
+
+        const unsigned long long has_pend = __ballot(np > 0);
+        bool go = has_pend != 0ull && (__ballot(np >= sc.pend_full) != 0ull || __ballot(cur >= 0) == 0ull ||
+                                       __popcll(has_pend) >= sc.pend_min);
+        while (go) {
+            RT_STAT(1, np > 0);
+            if (np > 0) {
+                int slot = ~pend[(ph & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK];
+                ph++;
+                np--;
+                    bool last;
+                    do {
+                        const float4* tp = sc.tris + 3 * (size_t)slot;
+                        const float4 a = tp[0], b = tp[1], c = tp[2];
+                        last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
+                        const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
+                        const V3 h = cross(d, e2); // IntersectTriRay2, Object.h:245-264
+                        const float det = dot(e1, h);
+                        if (!(det > -1e-7f && det < 1e-7f)) {
+                            const float f = 1.f / det;
+                            const V3 s = o - v0;
+                            const float u = f * dot(s, h);
+                            if (!(u < 0.f || u > 1.f)) {
+                                const V3 qq = cross(s, e1);
+                                const float v = f * dot(d, qq);
+                                if (!(v < 0.f || u + v > 1.f)) {
+                                    const float tt = f * dot(e2, qq);
+                                    if (tt > 0.0001f && !(tt > tmax) && !(tt < 0.f)) { // Object.h:260, 309-315
+                                        cur = RT_CUR_HIT;
+                                        np = 0;
+                                        sp = 0;
+                                        last = true;
+                                    }
+                                }
+                            }
+                        }
+                        slot++;
+                    } while (!last);
+            }
+            go = __ballot(np >= sc.pend_full) != 0ull || (__ballot(cur >= 0) == 0ull && __ballot(np > 0) != 0ull);
+        }
+        if (cur == RT_CUR_HIT || (cur == RT_CUR_FINISH && np == 0)) {
+            sink(q, cur == RT_CUR_HIT);
+            cur = RT_CUR_DONE;
+            exact = false;
+        }
+    }
+    RT_STAT_FLUSH(8);
 }
 
 // ---------------------------------------------------------------- shading

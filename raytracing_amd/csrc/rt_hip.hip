@@ -62,8 +62,14 @@ struct Wave {
     // dense shadow-ray queue
     float4* s_o;      // origin.xyz, tmax
     float4* s_d;      // dir.xyz, target index k*cap + q (bits)
-    // counters: [b*S + s] live rays of shard s entering bounce b (bounce 0: s = 0 only), [64*S + b*S + s] shadow rays
+    // counters: [b*S + s] live rays of shard s entering bounce b (bounce 0: shard s = the s-th shard_cap entries of the
+    // dense camera-ray queue), [64*S + b*S + s] shadow rays of shard s made at bounce b
+    // Counter i lives at word i * RT_CSTRIDE (one 128-byte line each).
     uint32_t* counts;
+    uint32_t* cursors; // same layout: rays of that queue shard handed out to traversal waves so far
+    uint32_t* counts_dense; // RT_COUNTS words: the counters gathered for the host at the end of a pass
+    uint32_t* type_counts;  // [(bounce * 16 + key) * RT_CSTRIDE]: queue entries of the bounce whose hit has material type key
+    uint32_t* perm;         // [key * capq + i]: their queue indices
 };
 
 struct PassParams {
@@ -94,7 +100,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     w.T_pdf[p] = make_float4(1.f, 1.f, 1.f, 1.f);
     w.rad[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     w.prev[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-    if (p == 0) w.counts[0] = (uint32_t)pp.cap;
+    if ((uint32_t)p < pp.n_shards) { // the dense camera-ray queue, cut into n_shards pieces for the traversal waves
+        const int64_t left = (int64_t)pp.cap - (int64_t)p * pp.shard_cap;
+        w.counts[(size_t)p * RT_CSTRIDE] = (uint32_t)(left < 0 ? 0 : (left > (int64_t)pp.shard_cap ? (int64_t)pp.shard_cap : left));
+    }
 }
 
 // Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup) and returns how many there are.
@@ -106,12 +115,12 @@ RT_DEV int stage_tree_top(const SceneView& sc, float4* s_top) {
 }
 
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                      const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
-                                                      float4* __restrict__ hit, int want_tri_id) {
+                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
+                                                      uint32_t n_shards, uint32_t shard_cap, float4* __restrict__ hit, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
     const int n_top = stage_tree_top(sc, s_top);
-    trace_queue<false>(sc, q_o, q_d, counts, n_shards, shard_cap, stack + threadIdx.x, s_top, n_top, [&](const RayState& r) {
+    trace_queue<false>(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, stack + threadIdx.x, s_top, n_top, [&](const RayState& r) {
         int slot = r.slot;
         if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
         hit[r.q] = make_float4(__int_as_float(slot), r.t, r.u, r.v);
@@ -120,22 +129,26 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const f
 
 // Dense shadow queue -> vis[target] = 1 when nothing blocks the segment.
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
-                                                     const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
-                                                     uint8_t* __restrict__ vis) {
+                                                     const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
+                                                     uint32_t n_shards, uint32_t shard_cap, uint8_t* __restrict__ vis) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
     const int n_top = stage_tree_top(sc, s_top);
-    trace_queue<true>(sc, s_o, s_d, counts, n_shards, shard_cap, stack + threadIdx.x, s_top, n_top,
-                      [&](const RayState& r) { vis[__float_as_uint(s_d[r.q].w)] = r.slot >= 0 ? 0 : 1; });
+    occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, stack + threadIdx.x, pend + threadIdx.x, s_top, n_top,
+                    [&](uint32_t q, bool occluded) { vis[__float_as_uint(s_d[q].w)] = occluded ? 0 : 1; });
 }
 
 // Parity hook variant: rays + tmax in, occluded flag out (rt_trace_any).
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                  const uint32_t* __restrict__ count, uint8_t* __restrict__ occ) {
+                                                  const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
+                                                  uint32_t shard_cap, uint8_t* __restrict__ occ) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
     const int n_top = stage_tree_top(sc, s_top);
-    trace_queue<true>(sc, q_o, q_d, count, 1u, 0u, stack + threadIdx.x, s_top, n_top, [&](const RayState& r) { occ[r.q] = r.slot >= 0 ? 1 : 0; });
+    occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, stack + threadIdx.x, pend + threadIdx.x, s_top, n_top,
+                    [&](uint32_t q, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
 
 // wave64 compaction over the lanes that call it (under divergence: the lanes of the current branch): ONE atomic per
@@ -157,49 +170,113 @@ RT_DEV uint32_t wave_reserve(uint32_t per_lane, bool extra, uint32_t* counter) {
 
 // Queue index -> is this entry live?  (uniform per workgroup: shard_cap is a multiple of RT_BLOCK)
 RT_DEV bool queue_entry_live(const Wave& w, const PassParams& pp, int bounce, uint32_t q, bool* block_idle) {
-    const uint32_t n_sh = bounce == 0 ? 1u : pp.n_shards;
-    const uint32_t cap_sh = bounce == 0 ? pp.capq : pp.shard_cap;
     const uint32_t bq = blockIdx.x * RT_BLOCK;
-    const uint32_t shard = bq / cap_sh;
-    if (shard >= n_sh) {
+    if (bounce == 0) { // dense: entries [0, cap)
+        *block_idle = bq >= (uint32_t)pp.cap;
+        return q < (uint32_t)pp.cap;
+    }
+    const uint32_t shard = bq / pp.shard_cap;
+    if (shard >= pp.n_shards) {
         *block_idle = true;
         return false;
     }
-    const uint32_t live = w.counts[(uint32_t)bounce * pp.n_shards + shard];
-    const uint32_t local0 = bq - shard * cap_sh;
+    const uint32_t live = w.counts[(size_t)((uint32_t)bounce * pp.n_shards + shard) * RT_CSTRIDE];
+    const uint32_t local0 = bq - shard * pp.shard_cap;
     *block_idle = local0 >= live;
-    return q - shard * cap_sh < live;
+    return q - shard * pp.shard_cap < live;
 }
+
+#ifdef RT_STATS // section timing of k_shade (debug builds only): cycles and lanes per section, spread over 256 rows
+__device__ unsigned long long g_shade_stats[256 * 32];
+#define SH_T0 unsigned long long sh_prev_ = __builtin_readcyclecounter();
+#define SH_MARK(i)                                                                                         \
+    do {                                                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                      \
+        const unsigned long long m_ = __ballot(true);                                                      \
+        if ((int)__lane_id() == __ffsll((long long)m_) - 1) {                                              \
+            atomicAdd(&g_shade_stats[(blockIdx.x & 255) * 32 + 2 * (i)], now_ - sh_prev_);                 \
+            atomicAdd(&g_shade_stats[(blockIdx.x & 255) * 32 + 2 * (i) + 1], (unsigned long long)__popcll(m_)); \
+        }                                                                                                  \
+        sh_prev_ = now_;                                                                                   \
+    } while (0)
+#else
+#define SH_T0
+#define SH_MARK(i)
+#endif
 
 #define RT_LDS_CDF 2048 // sampling tables up to this many entries are staged in LDS (8 KB + 16 KB per workgroup)
 
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, PassParams pp, int bounce, int last_bounce) {
-    // The two sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox); from LDS a step
-    // costs ~100 cycles instead of an L2 round trip.
-    __shared__ float s_env_cdf[RT_LDS_CDF];
-    __shared__ rt_emissive_tri s_emissive[RT_LDS_CDF];
-    const int in = bounce & 1, out = in ^ 1;
-    bool block_idle;
-    const bool live = queue_entry_live(w, pp, bounce, blockIdx.x * RT_BLOCK + threadIdx.x, &block_idle);
-    if (block_idle) return; // whole workgroup idle (uniform)
-    SceneView sc = sc_in;
-    {
-        const int n_env = sc_in.env_cdf ? sc_in.env_w * sc_in.env_h : 0;
-        if (n_env > 0 && n_env <= RT_LDS_CDF) {
-            for (int i = threadIdx.x; i < n_env; i += RT_BLOCK) s_env_cdf[i] = sc_in.env_cdf[i];
-            sc.env_cdf = s_env_cdf;
+// One k_shade_t<KEY> launch per material type present in the scene (+ one for rays that left the scene): k_classify
+// sorts the bounce's queue entries by the type of the material they hit, so every wave of a shading kernel runs ONE
+// material's Sample_Eval / Eval code at full lane occupancy instead of all the types its 64 rays happened to hit one
+// after the other (cornellbox: GGX walls, rough-dielectric and Disney-metal objects, emitters -> 4 code paths per wave).
+#define RT_KEY_MISS 12
+#define RT_N_KEYS 13
+
+// perm[key * capq + i] = queue index of the i-th entry whose hit has material type `key` (RT_KEY_MISS: no hit);
+// type_counts[(bounce * 16 + key) * RT_CSTRIDE] = how many.  Persistent workgroups: workgroup b takes every
+// (gridDim/n_shards)-th RT_BLOCK group of queue shard b % n_shards, counts its entries per key, reserves its part of
+// every key's list with ONE global atomic per key (a counter takes ~88 atomics/us: one per 256 entries was the whole
+// cost of this kernel), then walks its groups again and writes the indices.
+RT_DEV int classify_key(const SceneView& sc, const Wave& w, uint32_t q) {
+    const int slot = __float_as_int(w.hit[q].x);
+    return slot < 0 ? RT_KEY_MISS : (int)sc.tri_type[slot];
+}
+__global__ __launch_bounds__(RT_BLOCK) void k_classify(SceneView sc, Wave w, PassParams pp, int bounce) {
+    __shared__ uint32_t s_tot[16]; // entries of this workgroup per key, then the next free index in the key's list
+    const uint32_t lane = __lane_id();
+    const uint32_t shard = blockIdx.x % pp.n_shards, sub = blockIdx.x / pp.n_shards, n_sub = gridDim.x / pp.n_shards;
+    const uint32_t live = w.counts[(size_t)((uint32_t)bounce * pp.n_shards + shard) * RT_CSTRIDE];
+    if (sub * RT_BLOCK >= live) return; // uniform
+    const uint32_t q0 = shard * pp.shard_cap;
+    if (threadIdx.x < 16) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = sub * RT_BLOCK; base < live; base += n_sub * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < live) {
+            const int key = classify_key(sc, w, q0 + i);
+            for (;;) { // one ballot per key present in the wave; lanes leave as their key is handled
+                const int k = __builtin_amdgcn_readfirstlane(key);
+                const unsigned long long same = __ballot(key == k);
+                if (key == k) {
+                    if ((same & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&s_tot[k], (uint32_t)__popcll(same));
+                    break;
+                }
+            }
         }
-        if (sc_in.n_emissive > 0 && sc_in.n_emissive <= RT_LDS_CDF) {
-            for (int i = threadIdx.x; i < sc_in.n_emissive; i += RT_BLOCK) s_emissive[i] = sc_in.emissive[i];
-            sc.emissive = s_emissive;
-        }
-        __syncthreads();
     }
-    const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (!live) return;
-    // Everything below runs under divergence; wave_reserve() compacts over the lanes that reach it, which is all a
-    // dense queue needs.  This workgroup appends to output shard blockIdx.x % n_shards.
-    const uint32_t out_shard = blockIdx.x % pp.n_shards;
+    __syncthreads();
+    if (threadIdx.x < RT_N_KEYS) {
+        const uint32_t n = s_tot[threadIdx.x];
+        s_tot[threadIdx.x] = n ? atomicAdd(&w.type_counts[(size_t)(bounce * 16 + (int)threadIdx.x) * RT_CSTRIDE], n) : 0u;
+    }
+    __syncthreads();
+    for (uint32_t base = sub * RT_BLOCK; base < live; base += n_sub * RT_BLOCK) {
+        const uint32_t i = base + threadIdx.x;
+        if (i < live) {
+            const int key = classify_key(sc, w, q0 + i);
+            for (;;) {
+                const int k = __builtin_amdgcn_readfirstlane(key);
+                const unsigned long long same = __ballot(key == k);
+                if (key == k) {
+                    const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                    uint32_t first = 0;
+                    if (rank == 0) first = atomicAdd(&s_tot[k], (uint32_t)__popcll(same));
+                    first = __shfl(first, __ffsll((long long)same) - 1);
+                    w.perm[(size_t)k * pp.capq + first + rank] = q0 + i;
+                    break;
+                }
+            }
+        }
+    }
+}
+
+// Shades queue entry q whose hit has material type KEY.  Runs under divergence; wave_reserve() compacts over the
+// lanes that reach it, which is all a dense queue needs.  The workgroup appends to output shard `out_shard`.
+template <int KEY>
+RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp, int bounce, int last_bounce, uint32_t q, uint32_t out_shard) {
+    SH_T0
+    const int in = bounce & 1, out = in ^ 1;
     const float4 o4 = w.q_o[in][q], d4 = w.q_d[in][q], h4 = w.hit[q];
     const int p = __float_as_int(o4.w);
     const V3 ro(o4), rd(d4);
@@ -209,8 +286,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
     const float scatter_pdf = tp.w;
     V3 rad(w.rad[p]);
     float4 nee_T = make_float4(0.f, 0.f, 0.f, 0.f); // .w = 1 when this entry has NEE slots to resolve
+    SH_MARK(0); // queue + path state loads
 
-    if (slot < 0) { // main.cpp:340-359
+    if (KEY == RT_KEY_MISS) { // main.cpp:340-359
         if (pp.has_env) {
             float env_pdf;
             V3 bg = env_eval(sc, rd, &env_pdf);
@@ -220,6 +298,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
             w.rad[p] = pack(rad, 0.f);
         }
         w.q_T[q] = nee_T;
+        SH_MARK(1); // miss: environment lookup
         return;
     }
     // TriangleMesh::intersect tail, Object.h:350-355
@@ -232,7 +311,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
     N = normalize(N);
     si.front_face = dot(rd, N) < 0.f;
     si.normal = si.front_face ? N : -N;
-    const rt_material mat = sc.materials[mat_id];
+    rt_material mat = sc.materials[mat_id];
+    mat.type = KEY; // compile-time constant: the material switches below fold to this kernel's one case
 
     const float4 pv = w.prev[p];
     Rng rng;
@@ -258,8 +338,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
     }
     rad = rad + (weight * emitted) * T;
     w.rad[p] = pack(rad, 0.f);
+    SH_MARK(2); // surface, material fetch, emission
 
     Scatter scat = mat_sample(mat, si, rd, rng);
+    SH_MARK(3); // Sample_Eval
     if (fabsf(scat.pdf) < 0.000001f) { // main.cpp:410-412: the path ends BEFORE next-event estimation
         w.q_T[q] = nee_T;
         return;
@@ -283,9 +365,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
         w.contrib[q] = pack(env_c, 0.f);
         w.vis[q] = 0;
     }
+    SH_MARK(4); // environment NEE
     // one reservation for all of this wave's shadow rays: [env ray] + one per light, contiguous per lane
     uint32_t j = out_shard * (uint32_t)pp.K * pp.shard_cap +
-                 wave_reserve((uint32_t)sc.n_lights, want_env, &w.counts[64u * pp.n_shards + (uint32_t)bounce * pp.n_shards + out_shard]);
+                 wave_reserve((uint32_t)sc.n_lights, want_env, &w.counts[(size_t)(64u * pp.n_shards + (uint32_t)bounce * pp.n_shards + out_shard) * RT_CSTRIDE]);
     int k = 0;
     if (pp.has_env) {
         if (want_env) {
@@ -319,6 +402,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
         w.contrib[target] = pack(c, 0.f);
         w.vis[target] = 0;
     }
+    SH_MARK(5); // light NEE
     nee_T = pack(T, 1.f);
     w.q_T[q] = nee_T;
 
@@ -326,9 +410,55 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(SceneView sc_in, Wave w, Pas
     w.T_pdf[p] = pack(T, scat.pdf);
     w.prev[p] = pack(si.point, __uint_as_float(rng.ctr));
     if (!last_bounce) { // next-bounce ray queue, compacted over the surviving lanes
-        const uint32_t qi = out_shard * pp.shard_cap + wave_reserve(1u, false, &w.counts[(uint32_t)(bounce + 1) * pp.n_shards + out_shard]);
+        const uint32_t qi = out_shard * pp.shard_cap + wave_reserve(1u, false, &w.counts[(size_t)((uint32_t)(bounce + 1) * pp.n_shards + out_shard) * RT_CSTRIDE]);
         w.q_o[out][qi] = pack(scat.origin, __int_as_float(p));
         w.q_d[out][qi] = pack(scat.dir, 0.f);
+    }
+    SH_MARK(6); // path state + next ray
+}
+
+
+struct ShadeOrder { // the shading kernels of a bounce in launch order
+    int32_t n;
+    int32_t keys[RT_N_KEYS];
+};
+
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 1
+#endif
+template <int KEY>
+__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView sc_in, Wave w, PassParams pp, ShadeOrder order, int bounce, int last_bounce) {
+    // The two sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox); from LDS a step
+    // costs ~100 cycles instead of an L2 round trip.
+    __shared__ float s_env_cdf[RT_LDS_CDF];
+    __shared__ rt_emissive_tri s_emissive[RT_LDS_CDF];
+    const uint32_t n = w.type_counts[(size_t)(bounce * 16 + KEY) * RT_CSTRIDE];
+    if (blockIdx.x * RT_BLOCK >= n) return; // uniform: fewer entries than resident workgroups
+    SceneView sc = sc_in;
+    if (KEY != RT_KEY_MISS && KEY != RT_MAT_EMISSIVE) { // those two never reach next-event estimation
+        const int n_env = sc_in.env_cdf ? sc_in.env_w * sc_in.env_h : 0;
+        if (n_env > 0 && n_env <= RT_LDS_CDF) {
+            for (int i = threadIdx.x; i < n_env; i += RT_BLOCK) s_env_cdf[i] = sc_in.env_cdf[i];
+            sc.env_cdf = s_env_cdf;
+        }
+        if (sc_in.n_emissive > 0 && sc_in.n_emissive <= RT_LDS_CDF) {
+            for (int i = threadIdx.x; i < sc_in.n_emissive; i += RT_BLOCK) s_emissive[i] = sc_in.emissive[i];
+            sc.emissive = s_emissive;
+        }
+        __syncthreads();
+    }
+    // Output shards are filled round-robin by RT_BLOCK-entry groups numbered across all of the bounce's shading
+    // kernels (this kernel's groups follow those of the kernels launched before it), so no shard takes more than
+    // ceil(groups / n_shards) groups: at most (live entries / RT_BLOCK + one partial group per kernel) groups exist,
+    // which the spare group per shard in shard_cap covers.
+    uint32_t group0 = 0;
+    for (int k = 0; k < order.n && order.keys[k] != KEY; k++)
+        group0 += (w.type_counts[(size_t)(bounce * 16 + order.keys[k]) * RT_CSTRIDE] + RT_BLOCK - 1) / RT_BLOCK;
+    const uint32_t* perm = w.perm + (size_t)KEY * pp.capq;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) { // persistent, grid-stride
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t out_shard = (group0 + base / RT_BLOCK) % pp.n_shards;
+        if (i < n) shade_item<KEY>(sc, w, pp, bounce, last_bounce, perm[i], out_shard);
     }
 }
 
@@ -352,6 +482,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp,
 // pixel_total += s with the NaN guard of main.cpp:984-987, samples in index order
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(Wave w, PassParams pp, float* __restrict__ sum) {
     const int pix = blockIdx.x * RT_BLOCK + threadIdx.x;
+    for (int i = pix; i < RT_COUNTS; i += gridDim.x * RT_BLOCK) w.counts_dense[i] = w.counts[(size_t)i * RT_CSTRIDE];
     if (pix >= pp.npix) return;
     const int x = pp.x0 + pix % pp.tw, y = pp.y0 + pix / pp.tw;
     float* px = sum + ((size_t)y * pp.width + x) * 3;
@@ -383,11 +514,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
 // -------------------------------------------------------------- host side
 struct rt_scene {
     int device = 0;
-    unsigned persistent_blocks = 512; // resident 1024-thread traversal workgroups: CUs x 2 (32 waves per CU)
+    unsigned persistent_blocks = 16;  // resident traversal workgroups: 32 waves per CU, a multiple of RT_SHARDS waves in all
     hipStream_t stream = nullptr;
     SceneView view{};
     int64_t n_pairs = 0, n_tris = 0;
     int32_t n_materials = 0, n_lights = 0;
+    std::vector<int> keys; // material types some triangle uses, most triangles first, then RT_KEY_MISS
+    unsigned shade_blocks = 64; // resident workgroups of a shading launch (a multiple of RT_SHARDS)
     std::vector<void*> owned; // scene arrays
     // wavefront buffers
     Wave wave{};
@@ -446,10 +579,28 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K) {
     if ((rc = wave_alloc(s, &w.vis, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_o, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_d, kc))) return rc;
-    if ((rc = wave_alloc(s, &w.counts, (size_t)RT_COUNTS))) return rc;
+    if ((rc = wave_alloc(s, &w.counts, (size_t)3 * RT_COUNTS * RT_CSTRIDE))) return rc;
+    w.cursors = w.counts + (size_t)RT_COUNTS * RT_CSTRIDE;
+    w.type_counts = w.counts + (size_t)2 * RT_COUNTS * RT_CSTRIDE;
+    if ((rc = wave_alloc(s, &w.perm, c * RT_N_KEYS))) return rc;
+    if ((rc = wave_alloc(s, &w.counts_dense, (size_t)RT_COUNTS))) return rc;
     s->wave_cap = cap;
     s->wave_K = K;
     return RT_OK;
+}
+
+static void launch_shade(rt_scene* s, int key, const PassParams& pp, int bounce, int last_bounce) {
+    const dim3 g(s->shade_blocks), t(RT_BLOCK);
+    ShadeOrder order{};
+    order.n = (int32_t)s->keys.size();
+    for (size_t i = 0; i < s->keys.size(); i++) order.keys[i] = s->keys[i];
+#define RT_SHADE_CASE(K) \
+    case K: hipLaunchKernelGGL(k_shade_t<K>, g, t, 0, s->stream, s->view, s->wave, pp, order, bounce, last_bounce); break;
+    switch (key) {
+        RT_SHADE_CASE(0) RT_SHADE_CASE(1) RT_SHADE_CASE(2) RT_SHADE_CASE(3) RT_SHADE_CASE(4) RT_SHADE_CASE(5) RT_SHADE_CASE(6)
+        RT_SHADE_CASE(7) RT_SHADE_CASE(8) RT_SHADE_CASE(9) RT_SHADE_CASE(10) RT_SHADE_CASE(11) RT_SHADE_CASE(12)
+    }
+#undef RT_SHADE_CASE
 }
 
 static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + RT_BLOCK - 1) / RT_BLOCK); }
@@ -486,6 +637,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             return fail(RT_ERR_INVALID, "rt_scene_create: triangle material out of range");
         if (d->tris[i].light >= d->n_lights) return fail(RT_ERR_INVALID, "rt_scene_create: triangle light out of range");
     }
+    for (int32_t i = 0; i < d->n_materials; i++)
+        if (d->materials[i].type < 0 || d->materials[i].type >= RT_KEY_MISS) return fail(RT_ERR_INVALID, "rt_scene_create: unknown material type");
     for (int32_t i = 0; i < d->n_lights; i++) {
         const rt_light& L = d->lights[i];
         if (L.material < 0 || L.material >= d->n_materials) return fail(RT_ERR_INVALID, "rt_scene_create: light material out of range");
@@ -511,8 +664,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->device = device;
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            s->persistent_blocks = std::max(4u, ((unsigned)prop.multiProcessorCount * (2048u / RT_TRAV_BLOCK)) / 4u * 4u); // waves % RT_SHARDS == 0
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK; // workgroups per RT_SHARDS waves
+            s->persistent_blocks = std::max(wg_unit, ((unsigned)prop.multiProcessorCount * (2048u / RT_TRAV_BLOCK)) / wg_unit * wg_unit);
+            s->shade_blocks = std::max((unsigned)RT_SHARDS, ((unsigned)prop.multiProcessorCount * 4u) / RT_SHARDS * RT_SHARDS);
+        }
     }
     int rc = RT_OK;
     auto bail = [&](int code) {
@@ -539,14 +695,36 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         s->view.env_total = d->env_total;
         s->view.env_offset = d->env_offset;
     }
+    {
+        // k_classify's sort key per triangle slot, and the list of shading kernels this scene needs
+        std::vector<uint8_t> tri_type((size_t)d->n_tris);
+        int64_t per_type[RT_N_KEYS] = {};
+        for (int64_t i = 0; i < d->n_tris; i++) {
+            tri_type[(size_t)i] = (uint8_t)d->materials[d->tris[i].material].type;
+            per_type[tri_type[(size_t)i]]++;
+        }
+        if ((rc = upload(s, tri_type.data(), tri_type.size(), &s->view.tri_type))) return bail(rc);
+        for (int k = 0; k < RT_KEY_MISS; k++)
+            if (per_type[k]) s->keys.push_back(k);
+        std::sort(s->keys.begin(), s->keys.end(), [&](int a, int b) { return per_type[a] > per_type[b]; });
+        s->keys.push_back(RT_KEY_MISS);
+    }
     s->view.pairs = (const float4*)pairs;
     s->view.tris = (const float4*)tris;
     s->view.normals = (const float4*)normals;
     s->view.root_ref = d->root_ref;
-    s->view.refill_min = 24;
+    s->view.refill_min = 16;
     s->view.leaf_min = 16;
+    s->view.pend_min = 32;
+    s->view.pend_full = 3;
+    s->view.wave_min_rays = 0;
+    s->view.fetch_chunk = 128;
     if (const char* e = getenv("RT_TUNE_REFILL_MIN")) s->view.refill_min = std::max(1, atoi(e));
     if (const char* e = getenv("RT_TUNE_LEAF_MIN")) s->view.leaf_min = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_TUNE_PEND_MIN")) s->view.pend_min = std::max(1, atoi(e));
+    if (const char* e = getenv("RT_TUNE_PEND_FULL")) s->view.pend_full = std::min(RT_PEND_FULL_MAX, std::max(1, atoi(e)));
+    if (const char* e = getenv("RT_TUNE_WAVE_MIN")) s->view.wave_min_rays = std::max(0, atoi(e));
+    if (const char* e = getenv("RT_TUNE_FETCH_CHUNK")) s->view.fetch_chunk = std::max(64, atoi(e) / 64 * 64);
     s->view.n_lights = d->n_lights;
     s->view.n_emissive = d->n_emissive_tris;
     s->view.n_pairs = (int32_t)std::min<int64_t>(d->n_pairs, 0x7fffffff);
@@ -610,15 +788,20 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     } while (0)
     TRY(hipMalloc((void**)&d_o, (size_t)n * sizeof(float4)));
     TRY(hipMalloc((void**)&d_d, (size_t)n * sizeof(float4)));
-    TRY(hipMalloc((void**)&d_count, 2 * sizeof(uint32_t)));
+    TRY(hipMalloc((void**)&d_count, 2 * RT_SHARDS * RT_CSTRIDE * sizeof(uint32_t)));
     TRY(hipMemcpyAsync(d_o, o.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     TRY(hipMemcpyAsync(d_d, d.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-    const uint32_t n32[2] = {(uint32_t)n, 0u}; // ray count, fetch cursor
-    TRY(hipMemcpyAsync(d_count, n32, sizeof(n32), hipMemcpyHostToDevice, s->stream));
-    const unsigned grid = std::min((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK), s->persistent_blocks);
+    // the caller's array is cut into RT_SHARDS consecutive pieces, each with its own fetch cursor (rt_device.h, QueueShare)
+    const int64_t piece = ((n + RT_SHARDS - 1) / RT_SHARDS + 63) / 64 * 64;
+    std::vector<uint32_t> n32((size_t)2 * RT_SHARDS * RT_CSTRIDE, 0u); // counts, then cursors
+    for (int64_t sh = 0; sh < RT_SHARDS; sh++) n32[(size_t)sh * RT_CSTRIDE] = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(piece, n - sh * piece));
+    TRY(hipMemcpyAsync(d_count, n32.data(), n32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK; // workgroups per RT_SHARDS waves
+    const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
     if (hits) {
         TRY(hipMalloc((void**)&d_hit, (size_t)n * sizeof(float4)));
-        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, 1u, 0u, d_hit, 1);
+        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                           (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, 1);
         TRY(hipGetLastError());
         std::vector<float4> h((size_t)n);
         TRY(hipMemcpyAsync(h.data(), d_hit, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
@@ -633,7 +816,8 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
         }
     } else {
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
-        hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_occ);
+        hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                           (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, s->stream));
         TRY(hipStreamSynchronize(s->stream));
@@ -665,7 +849,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     if (spp_pass <= 0) spp_pass = (int)std::max<int64_t>(1, (int64_t)(8 << 20) / npix);
     spp_pass = std::min(spp_pass, o->spp_count);
     const int64_t cap = npix * spp_pass;
-    const int64_t shard_cap = ((cap + (int64_t)RT_SHARDS * RT_BLOCK - 1) / ((int64_t)RT_SHARDS * RT_BLOCK)) * RT_BLOCK;
+    // entries per queue shard: its share of the paths plus one spare RT_BLOCK group (see k_shade_t)
+    const int64_t shard_cap = ((cap + (int64_t)RT_SHARDS * RT_BLOCK - 1) / ((int64_t)RT_SHARDS * RT_BLOCK) + 1) * RT_BLOCK;
     const int64_t capq = shard_cap * RT_SHARDS;
     if (cap > (int64_t)1 << 30) return fail(RT_ERR_LIMIT, "rt_render: more than 2^30 paths per pass; lower spp_per_pass");
     const bool has_env = s->view.env_rgb != nullptr;
@@ -733,26 +918,26 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         const unsigned grid0 = blocks_for(pp.cap);   // bounce-0 queue is dense
         const unsigned gridq = blocks_for(pp.capq);  // later queues are sharded
         const unsigned pgrid = s->persistent_blocks; // persistent traversal launches (multiple of RT_SHARDS waves)
-        HIPCHK(hipMemsetAsync(s->wave.counts, 0, RT_COUNTS * sizeof(uint32_t), s->stream));
+        HIPCHK(hipMemsetAsync(s->wave.counts, 0, (size_t)3 * RT_COUNTS * RT_CSTRIDE * sizeof(uint32_t), s->stream)); // counts, cursors, type counts
         mark();
         hipLaunchKernelGGL(k_generate, dim3(grid0), dim3(RT_BLOCK), 0, s->stream, s->wave, pp);
         mark();
         for (int b = 0; b < o->max_depth; b++) {
             const int in = b & 1;
-            uint32_t* ray_counts = s->wave.counts + (size_t)b * RT_SHARDS;
-            uint32_t* shadow_counts = s->wave.counts + (size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS;
+            uint32_t* ray_counts = s->wave.counts + (size_t)b * RT_SHARDS * RT_CSTRIDE;
+            uint32_t* shadow_counts = s->wave.counts + ((size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS) * RT_CSTRIDE;
             mark();
-            hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view,
-                               s->wave.q_o[in], s->wave.q_d[in], ray_counts, b == 0 ? 1u : (uint32_t)RT_SHARDS, pp.shard_cap, s->wave.hit, 0);
+            hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, s->wave.q_o[in], s->wave.q_d[in],
+                               ray_counts, ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, s->wave.hit, 0);
             mark();
             mark();
-            hipLaunchKernelGGL(k_shade, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave, pp, b,
-                               b == o->max_depth - 1 ? 1 : 0);
+            hipLaunchKernelGGL(k_classify, dim3(s->shade_blocks), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave, pp, b);
+            for (int key : s->keys) launch_shade(s, key, pp, b, b == o->max_depth - 1 ? 1 : 0);
             mark();
             mark();
             if (K > 0)
                 hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, s->wave.s_o, s->wave.s_d, shadow_counts,
-                                   (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, s->wave.vis);
+                                   shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, s->wave.vis);
             mark();
             mark();
             if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, b);
@@ -762,7 +947,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(npix)), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, d_sum);
         mark();
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&h_counts[(size_t)pass * RT_COUNTS], s->wave.counts, RT_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&h_counts[(size_t)pass * RT_COUNTS], s->wave.counts_dense, RT_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     }
     HIPCHK(hipEventRecord(s->ev_end, s->stream));
     if (!dev_out) HIPCHK(hipMemcpyAsync(radiance_sum, d_sum, sum_n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
@@ -772,7 +957,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         rt_stats st{};
         for (int pass = 0; pass < n_pass; pass++) {
             const uint32_t* c = &h_counts[(size_t)pass * RT_COUNTS];
-            st.paths += c[0];
+            for (int sh = 0; sh < RT_SHARDS; sh++) st.paths += c[sh];
             for (int b = 0; b < o->max_depth; b++) {
                 uint64_t nc = 0, ns = 0;
                 for (int sh = 0; sh < RT_SHARDS; sh++) {
@@ -819,6 +1004,29 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     }
     return RT_OK;
 }
+
+#ifdef RT_STATS
+// debug builds only: reads and clears the lane-occupancy counters ([0..7] closest walk, [8..15] occlusion walk;
+// pairs of {wave-level steps, lanes active in them}: inner steps, leaf turns, -, rounds)
+int rt_debug_lane_stats(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rt_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rt_stats), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
+// k_shade sections: out32[2*i] = summed wave cycles of section i, out32[2*i+1] = summed lanes that reached its end
+int rt_debug_shade_stats(unsigned long long* out32) {
+    static unsigned long long host[256 * 32];
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_shade_stats), sizeof(host)) != hipSuccess) return RT_ERR_HIP;
+    for (int i = 0; i < 32; i++) {
+        out32[i] = 0;
+        for (int r = 0; r < 256; r++) out32[i] += host[r * 32 + i];
+    }
+    std::memset(host, 0, sizeof(host));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_shade_stats), host, sizeof(host)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
+#endif
 
 int rt_resolve(rt_scene* s, const float* radiance_sum, int32_t width, int32_t height, int32_t spp, float gamma, uint8_t* rgb_out) {
     if (!s || !radiance_sum || !rgb_out || width <= 0 || height <= 0 || spp <= 0) return fail(RT_ERR_INVALID, "rt_resolve: bad argument");

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Lane occupancy of the traversal loops on the bench workload (needs a -DRT_STATS build copied over librt_hip.so:
+tools/lane_stats.sh).  Prints, per walk, wave-level step counts and the mean number of lanes active in them."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import raytracing_amd as rta
+import scenes
+
+lib = C.CDLL(os.path.join(ROOT, "raytracing_amd", "librt_hip.so"), mode=C.RTLD_GLOBAL)
+buf = (C.c_ulonglong * 16)()
+sc = scenes.cornellbox(rta)
+sc.build()
+sc.upload(0)
+cam = scenes.cornell_camera(rta, sc, 1920, 1080)
+sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=0, spp_total=1024)
+lib.rt_debug_lane_stats(buf)  # warm-up discarded
+_, st = sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=4, spp_total=1024)
+assert lib.rt_debug_lane_stats(buf) == 0
+v = list(buf)
+for name, base, rays in (("closest", 0, st["rays_closest"]), ("occlusion", 8, st["rays_shadow"])):
+    inner_w, inner_l, leaf_w, leaf_l, _, _, rounds, held = v[base:base + 8]
+    print(f"{name}: rays {rays}  rounds {rounds} (lanes holding a ray {held / max(rounds, 1):.1f})")
+    print(f"  inner steps: {inner_w} wave-steps, {inner_l / max(inner_w, 1):.1f} lanes each, {inner_l / rays:.2f} per ray")
+    print(f"  leaf turns : {leaf_w} wave-turns, {leaf_l / max(leaf_w, 1):.1f} lanes each, {leaf_l / rays:.2f} per ray")
+
+sbuf = (C.c_ulonglong * 32)()
+if hasattr(lib, "rt_debug_shade_stats"):
+    lib.rt_debug_shade_stats(sbuf)
+    sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=8, spp_total=1024)
+    lib.rt_debug_shade_stats(sbuf)
+    names = ["loads", "miss/env lookup", "surface+emission", "Sample_Eval", "env NEE", "light NEE", "state+next ray", "(miss lanes waiting)"]
+    tot = sum(sbuf[2 * i] for i in range(7))
+    print("k_shade sections (wave cycles share, wave visits are not counted: lanes = lanes at the section's end / 1e6)")
+    for i, n in enumerate(names):
+        print(f"  {n:22s} {100.0 * sbuf[2 * i] / tot:5.1f} %   lanes {sbuf[2 * i + 1] / 1e6:8.2f} M")

@@ -14,12 +14,12 @@ calls = defaultdict(lambda: defaultdict(set))
 dur = defaultdict(float)
 for path in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
     for row in csv.DictReader(open(path)):
-        k = row["Kernel_Name"].split("(")[0]
+        k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
         calls[k][row["Counter_Name"]].add(row["Dispatch_Id"])
 for path in glob.glob(os.path.join(root, "sq1", "*", "*_kernel_trace.csv")):
     for row in csv.DictReader(open(path)):
-        dur[row["Kernel_Name"].split("(")[0]] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+        dur[row["Kernel_Name"].split("(")[0].replace("void ", "")] += (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
 out = {}
 for k, c in sorted(tot.items()):
     if not k.startswith("k_"):
