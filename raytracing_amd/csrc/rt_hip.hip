@@ -522,11 +522,17 @@ struct rt_scene {
     std::vector<int> keys; // material types some triangle uses, most triangles first, then RT_KEY_MISS
     unsigned shade_blocks = 64; // resident workgroups of a shading launch (a multiple of RT_SHARDS)
     std::vector<void*> owned; // scene arrays
-    // wavefront buffers
-    Wave wave{};
+    // wavefront buffers: two sets, so that consecutive sample passes of one rt_render call can run on two streams
+    Wave wave[2] = {};
     int64_t wave_cap = 0;
     int wave_K = 0;
+    int wave_sets = 0;
     std::vector<void*> wave_owned;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_acc[2] = {nullptr, nullptr};
+    uint32_t* h_counts = nullptr; // pinned: per-pass counter read-back must not block the launching thread
+    size_t h_counts_n = 0;
+    unsigned pipe_blocks = 16; // traversal workgroups per launch while two passes share the GPU
     float* d_sum = nullptr;
     int64_t d_sum_n = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -549,6 +555,7 @@ static void free_wave(rt_scene* s) {
     for (void* p : s->wave_owned) (void)hipFree(p);
     s->wave_owned.clear();
     s->wave_cap = 0;
+    s->wave_sets = 0;
 }
 
 template <typename T>
@@ -560,12 +567,13 @@ static int wave_alloc(rt_scene* s, T** out, size_t n) {
     return RT_OK;
 }
 
-static int ensure_wave(rt_scene* s, int64_t cap, int K) {
-    if (s->wave_cap >= cap && s->wave_K >= K) return RT_OK;
+static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
+    if (s->wave_cap >= cap && s->wave_K >= K && s->wave_sets >= sets) return RT_OK;
     free_wave(s);
-    Wave& w = s->wave;
     const size_t c = (size_t)cap, kc = (size_t)cap * (size_t)(K > 0 ? K : 1);
     int rc;
+    for (int set = 0; set < sets; set++) {
+    Wave& w = s->wave[set];
     for (int i = 0; i < 2; i++) {
         if ((rc = wave_alloc(s, &w.q_o[i], c))) return rc;
         if ((rc = wave_alloc(s, &w.q_d[i], c))) return rc;
@@ -584,18 +592,20 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K) {
     w.type_counts = w.counts + (size_t)2 * RT_COUNTS * RT_CSTRIDE;
     if ((rc = wave_alloc(s, &w.perm, c * RT_N_KEYS))) return rc;
     if ((rc = wave_alloc(s, &w.counts_dense, (size_t)RT_COUNTS))) return rc;
+    }
     s->wave_cap = cap;
     s->wave_K = K;
+    s->wave_sets = sets;
     return RT_OK;
 }
 
-static void launch_shade(rt_scene* s, int key, const PassParams& pp, int bounce, int last_bounce) {
+static void launch_shade(rt_scene* s, hipStream_t st, const Wave& wave, int key, const PassParams& pp, int bounce, int last_bounce) {
     const dim3 g(s->shade_blocks), t(RT_BLOCK);
     ShadeOrder order{};
     order.n = (int32_t)s->keys.size();
     for (size_t i = 0; i < s->keys.size(); i++) order.keys[i] = s->keys[i];
 #define RT_SHADE_CASE(K) \
-    case K: hipLaunchKernelGGL(k_shade_t<K>, g, t, 0, s->stream, s->view, s->wave, pp, order, bounce, last_bounce); break;
+    case K: hipLaunchKernelGGL(k_shade_t<K>, g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce); break;
     switch (key) {
         RT_SHADE_CASE(0) RT_SHADE_CASE(1) RT_SHADE_CASE(2) RT_SHADE_CASE(3) RT_SHADE_CASE(4) RT_SHADE_CASE(5) RT_SHADE_CASE(6)
         RT_SHADE_CASE(7) RT_SHADE_CASE(8) RT_SHADE_CASE(9) RT_SHADE_CASE(10) RT_SHADE_CASE(11) RT_SHADE_CASE(12)
@@ -668,6 +678,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK; // workgroups per RT_SHARDS waves
             s->persistent_blocks = std::max(wg_unit, ((unsigned)prop.multiProcessorCount * (2048u / RT_TRAV_BLOCK)) / wg_unit * wg_unit);
             s->shade_blocks = std::max((unsigned)RT_SHARDS, ((unsigned)prop.multiProcessorCount * 4u) / RT_SHARDS * RT_SHARDS);
+            if (const char* e = getenv("RT_TUNE_PERSIST_EIGHTHS")) // traversal grid as eighths of full occupancy
+                s->persistent_blocks = std::max(wg_unit, s->persistent_blocks * (unsigned)std::max(1, std::min(8, atoi(e))) / 8u / wg_unit * wg_unit);
+            // two passes in flight: each pass's traversal launches take half the wave slots, so the other pass's
+            // kernels (memory-bound shading against VALU-bound traversal) find room beside them
+            unsigned pipe_eighths = 4;
+            if (const char* e = getenv("RT_TUNE_PIPE_EIGHTHS")) pipe_eighths = (unsigned)std::max(1, std::min(8, atoi(e)));
+            s->pipe_blocks = std::max(wg_unit, s->persistent_blocks * pipe_eighths / 8u / wg_unit * wg_unit);
         }
     }
     int rc = RT_OK;
@@ -676,7 +693,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         return code;
     };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
-    if (hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess)
+    if (hipStreamCreateWithFlags(&s->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipStreamCreate failed"));
+    if (hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_acc[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->ev_acc[1], hipEventDisableTiming) != hipSuccess)
         return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
     const rt_bvh_pair* pairs;
     const rt_tri* tris;
@@ -740,10 +761,15 @@ void rt_scene_destroy(rt_scene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    if (s->stream2) (void)hipStreamSynchronize(s->stream2);
     free_wave(s);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->d_sum) (void)hipFree(s->d_sum);
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {s->ev_fork, s->ev_acc[0], s->ev_acc[1]})
+        if (e) (void)hipEventDestroy(e);
+    if (s->stream2) (void)hipStreamDestroy(s->stream2);
     if (s->ev_begin) (void)hipEventDestroy(s->ev_begin);
     if (s->ev_end) (void)hipEventDestroy(s->ev_end);
     if (s->stream) (void)hipStreamDestroy(s->stream);
@@ -855,8 +881,19 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     if (cap > (int64_t)1 << 30) return fail(RT_ERR_LIMIT, "rt_render: more than 2^30 paths per pass; lower spp_per_pass");
     const bool has_env = s->view.env_rgb != nullptr;
     const int K = (has_env ? 1 : 0) + s->n_lights;
+    const int n_pass = (o->spp_count + spp_pass - 1) / spp_pass;
+    // Sample passes are independent until their sums are added to the frame: with two or more, pass i runs on
+    // stream i % 2 with its own buffer set, and only the accumulation kernels are ordered (pass order, by events).
+    const int sets = (n_pass >= 2 && !getenv("RT_TUNE_ONE_STREAM")) ? 2 : 1;
     int rc;
-    if ((rc = ensure_wave(s, capq, K))) return rc;
+    if ((rc = ensure_wave(s, capq, K, sets))) return rc;
+    if (s->h_counts_n < (size_t)n_pass * RT_COUNTS) {
+        if (s->h_counts) (void)hipHostFree(s->h_counts);
+        s->h_counts = nullptr;
+        s->h_counts_n = 0;
+        HIPCHK(hipHostMalloc((void**)&s->h_counts, (size_t)n_pass * RT_COUNTS * sizeof(uint32_t)));
+        s->h_counts_n = (size_t)n_pass * RT_COUNTS;
+    }
 
     // accumulation target
     const size_t sum_n = (size_t)o->width * o->height * 3;
@@ -878,7 +915,6 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     if (o->flags & RT_RENDER_CLEAR) HIPCHK(hipMemsetAsync(d_sum, 0, sum_n * sizeof(float), s->stream));
 
     const bool timing = (o->flags & RT_RENDER_TIMING) != 0;
-    const int n_pass = (o->spp_count + spp_pass - 1) / spp_pass;
     // event pairs per pass: generate, accumulate, and closest/shade/shadow/resolve per bounce
     const size_t ev_per_pass = 2 * (2 + 4 * (size_t)o->max_depth);
     if (timing) {
@@ -890,13 +926,21 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         }
     }
     size_t ev_next = 0;
+    hipStream_t st = s->stream;
     auto mark = [&]() {
-        if (timing) (void)hipEventRecord(s->ev_pool[ev_next++], s->stream);
+        if (timing) (void)hipEventRecord(s->ev_pool[ev_next++], st);
     };
 
-    std::vector<uint32_t> h_counts((size_t)n_pass * RT_COUNTS);
+    uint32_t* h_counts = s->h_counts;
     HIPCHK(hipEventRecord(s->ev_begin, s->stream));
+    if (sets == 2) { // the second stream starts once the frame buffer is ready
+        HIPCHK(hipEventRecord(s->ev_fork, s->stream));
+        HIPCHK(hipStreamWaitEvent(s->stream2, s->ev_fork, 0));
+    }
     for (int pass = 0; pass < n_pass; pass++) {
+        const int set = sets == 2 ? (pass & 1) : 0;
+        st = set ? s->stream2 : s->stream;
+        const Wave& wave = s->wave[set];
         PassParams pp;
         pp.cam = *cam;
         pp.width = o->width;
@@ -917,41 +961,47 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         pp.capq = (uint32_t)capq;
         const unsigned grid0 = blocks_for(pp.cap);   // bounce-0 queue is dense
         const unsigned gridq = blocks_for(pp.capq);  // later queues are sharded
-        const unsigned pgrid = s->persistent_blocks; // persistent traversal launches (multiple of RT_SHARDS waves)
-        HIPCHK(hipMemsetAsync(s->wave.counts, 0, (size_t)3 * RT_COUNTS * RT_CSTRIDE * sizeof(uint32_t), s->stream)); // counts, cursors, type counts
+        const unsigned pgrid = sets == 2 ? s->pipe_blocks : s->persistent_blocks; // persistent traversal launches (multiple of RT_SHARDS waves)
+        HIPCHK(hipMemsetAsync(wave.counts, 0, (size_t)3 * RT_COUNTS * RT_CSTRIDE * sizeof(uint32_t), st)); // counts, cursors, type counts
         mark();
-        hipLaunchKernelGGL(k_generate, dim3(grid0), dim3(RT_BLOCK), 0, s->stream, s->wave, pp);
+        hipLaunchKernelGGL(k_generate, dim3(grid0), dim3(RT_BLOCK), 0, st, wave, pp);
         mark();
         for (int b = 0; b < o->max_depth; b++) {
             const int in = b & 1;
-            uint32_t* ray_counts = s->wave.counts + (size_t)b * RT_SHARDS * RT_CSTRIDE;
-            uint32_t* shadow_counts = s->wave.counts + ((size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS) * RT_CSTRIDE;
+            uint32_t* ray_counts = wave.counts + (size_t)b * RT_SHARDS * RT_CSTRIDE;
+            uint32_t* shadow_counts = wave.counts + ((size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS) * RT_CSTRIDE;
             mark();
-            hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, s->wave.q_o[in], s->wave.q_d[in],
-                               ray_counts, ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, s->wave.hit, 0);
+            hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in],
+                               ray_counts, ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, 0);
             mark();
             mark();
-            hipLaunchKernelGGL(k_classify, dim3(s->shade_blocks), dim3(RT_BLOCK), 0, s->stream, s->view, s->wave, pp, b);
-            for (int key : s->keys) launch_shade(s, key, pp, b, b == o->max_depth - 1 ? 1 : 0);
+            hipLaunchKernelGGL(k_classify, dim3(s->shade_blocks), dim3(RT_BLOCK), 0, st, s->view, wave, pp, b);
+            for (int key : s->keys) launch_shade(s, st, wave, key, pp, b, b == o->max_depth - 1 ? 1 : 0);
             mark();
             mark();
             if (K > 0)
-                hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, s->wave.s_o, s->wave.s_d, shadow_counts,
-                                   shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, s->wave.vis);
+                hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
+                                   shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);
             mark();
             mark();
-            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, b);
+            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, st, wave, pp, b);
             mark();
         }
         mark();
-        hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(npix)), dim3(RT_BLOCK), 0, s->stream, s->wave, pp, d_sum);
+        if (sets == 2 && pass > 0) HIPCHK(hipStreamWaitEvent(st, s->ev_acc[(pass - 1) & 1], 0)); // frame adds in pass order
+        hipLaunchKernelGGL(k_accumulate, dim3(blocks_for(npix)), dim3(RT_BLOCK), 0, st, wave, pp, d_sum);
         mark();
+        if (sets == 2) HIPCHK(hipEventRecord(s->ev_acc[pass & 1], st));
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&h_counts[(size_t)pass * RT_COUNTS], s->wave.counts_dense, RT_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(hipMemcpyAsync(&h_counts[(size_t)pass * RT_COUNTS], wave.counts_dense, RT_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    }
+    if (sets == 2) { // join: the last accumulation (which waited for all earlier ones) and the other stream's read-backs
+        HIPCHK(hipStreamWaitEvent(s->stream, s->ev_acc[(n_pass - 1) & 1], 0));
     }
     HIPCHK(hipEventRecord(s->ev_end, s->stream));
     if (!dev_out) HIPCHK(hipMemcpyAsync(radiance_sum, d_sum, sum_n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (sets == 2) HIPCHK(hipStreamSynchronize(s->stream2));
 
     if (stats) {
         rt_stats st{};
