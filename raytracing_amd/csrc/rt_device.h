@@ -163,6 +163,32 @@ RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv
 // ONE atomic, so rays of a shard go to whichever of its waves has room: no wave is left holding a long static share
 // while others have finished.  One cursor for the whole queue would saturate (~88 same-address atomics/us on MI355X);
 // 64 shards keep every address far below that.  Rays handed to one wave are consecutive: the fetch is coalesced.
+// IntersectTriRay2 (Object.h:245-264, edges pre-differenced by the host) followed by the acceptance test of
+// TriangleMesh::intersect (Object.h:260, 309-315 with tmin = 0).  ONE definition for every caller (closest walk,
+// occlusion walk), so that both accept exactly the same (ray, triangle, tmax) triples.
+// `a > -1e-7 && a < 1e-7` is written in double in the reference; float(1e-7) is the smallest float above the double
+// 1e-7, so the fp32 compare accepts the same set.
+RT_DEV bool tri_accept(const V3& o, const V3& d, const float4& a, const float4& b, const float4& c, float tmax, float* t_out,
+                       float* u_out, float* v_out) {
+    const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
+    const V3 h = cross(d, e2);
+    const float det = dot(e1, h);
+    if (det > -1e-7f && det < 1e-7f) return false;
+    const float f = 1.f / det;
+    const V3 s = o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.f || u > 1.f) return false;
+    const V3 qq = cross(s, e1);
+    const float v = f * dot(d, qq);
+    if (v < 0.f || u + v > 1.f) return false;
+    const float tt = f * dot(e2, qq);
+    if (!(tt > 0.0001f && !(tt > tmax) && !(tt < 0.f))) return false;
+    *t_out = tt;
+    *u_out = u;
+    *v_out = v;
+    return true;
+}
+
 #ifdef RT_STATS // lane-occupancy instrumentation of the traversal loops (debug builds only: tools/lane_stats.sh)
 __device__ unsigned long long g_rt_stats[16];
 #define RT_STAT_DECL unsigned st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -337,32 +363,14 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                     const float4* tp = sc.tris + 3 * (size_t)slot;
                     const float4 a = tp[0], b = tp[1], c = tp[2];
                     last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
-                    // IntersectTriRay2, Object.h:245-264 (edges pre-differenced by the host)
-                    const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
-                    const V3 h = cross(r.d, e2);
-                    const float det = dot(e1, h);
-                    // `a > -1e-7 && a < 1e-7` is written in double in the reference; float(1e-7) is the
-                    // smallest float above the double 1e-7, so the fp32 compare accepts the same set.
-                    if (!(det > -1e-7f && det < 1e-7f)) {
-                        const float f = 1.f / det;
-                        const V3 s = r.o - v0;
-                        const float u = f * dot(s, h);
-                        if (!(u < 0.f || u > 1.f)) {
-                            const V3 qq = cross(s, e1);
-                            const float v = f * dot(r.d, qq);
-                            if (!(v < 0.f || u + v > 1.f)) {
-                                const float tt = f * dot(e2, qq);
-                                // Object.h:260 and 309-315 with tmin = 0
-                                if (tt > 0.0001f && !(tt > r.tmax) && !(tt < 0.f)) {
-                                    r.tmax = tt;
-                                    r.t = tt;
-                                    r.slot = slot;
-                                    r.u = u;
-                                    r.v = v;
-                                    if (ANY) last = true;
-                                }
-                            }
-                        }
+                    float tt, u, v;
+                    if (tri_accept(r.o, r.d, a, b, c, r.tmax, &tt, &u, &v)) {
+                        r.tmax = tt;
+                        r.t = tt;
+                        r.slot = slot;
+                        r.u = u;
+                        r.v = v;
+                        if (ANY) last = true;
                     }
                     slot++;
                 } while (!last);
@@ -383,8 +391,10 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 }
 
 #define RT_CUR_HIT ((int)0x80000002)    // occlusion_queue: an occluder was found
-#define RT_PEND_CAP 8      // pending-leaf ring per lane in LDS (occlusion_queue); a power of two
-#define RT_PEND_FULL_MAX 5 // a round of two inner steps adds at most 4 entries, so it must start with <= 4
+#ifndef RT_PEND_CAP
+#define RT_PEND_CAP 8 // pending-leaf ring per lane in LDS (occlusion_queue); a power of two
+#endif
+#define RT_PEND_FULL_MAX (RT_PEND_CAP - 3) // a round of two inner steps adds at most 4 entries: it starts with <= CAP - 4
 
 // Boolean occlusion (trace_scene as used at main.cpp:250,281) over a dense ray queue.  The answer of the reference's
 // any-hit walk does not depend on the order of its steps: its `t` stays infinite until the first accepted triangle
@@ -503,26 +513,12 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                         const float4* tp = sc.tris + 3 * (size_t)slot;
                         const float4 a = tp[0], b = tp[1], c = tp[2];
                         last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
-                        const V3 e1(b.x, b.y, b.z), e2(c.x, c.y, c.z), v0(a.x, a.y, a.z);
-                        const V3 h = cross(d, e2); // IntersectTriRay2, Object.h:245-264
-                        const float det = dot(e1, h);
-                        if (!(det > -1e-7f && det < 1e-7f)) {
-                            const float f = 1.f / det;
-                            const V3 s = o - v0;
-                            const float u = f * dot(s, h);
-                            if (!(u < 0.f || u > 1.f)) {
-                                const V3 qq = cross(s, e1);
-                                const float v = f * dot(d, qq);
-                                if (!(v < 0.f || u + v > 1.f)) {
-                                    const float tt = f * dot(e2, qq);
-                                    if (tt > 0.0001f && !(tt > tmax) && !(tt < 0.f)) { // Object.h:260, 309-315
-                                        cur = RT_CUR_HIT;
-                                        np = 0;
-                                        sp = 0;
-                                        last = true;
-                                    }
-                                }
-                            }
+                        float tt, u, v;
+                        if (tri_accept(o, d, a, b, c, tmax, &tt, &u, &v)) {
+                            cur = RT_CUR_HIT;
+                            np = 0;
+                            sp = 0;
+                            last = true;
                         }
                         slot++;
                     } while (!last);
