@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-pass", type=int, default=0)
+    ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,11 +96,12 @@ def main():
     cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
 
     K, W = args.steps, args.warmup
-    first, _, spp_total = sharding.sample_window(rank, world, K * SPP_STEP)  # this rank's window of the Hammersley set
+    spp_step = args.spp_step
+    first, _, spp_total = sharding.sample_window(rank, world, K * spp_step)  # this rank's window of the Hammersley set
     frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step(i, timing):
-        _, st = sc.render(cam, WIDTH, HEIGHT, spp=SPP_STEP, max_depth=DEPTH, seed=1, spp_begin=first + (i % K) * SPP_STEP,
+        _, st = sc.render(cam, WIDTH, HEIGHT, spp=spp_step, max_depth=DEPTH, seed=1, spp_begin=first + (i % K) * spp_step,
                           spp_total=spp_total, spp_per_pass=args.spp_per_pass, device_out=frame.data_ptr(), timing=timing)
         return st
 
@@ -152,14 +154,14 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"cornellbox.glb {WIDTH}x{HEIGHT}, {DEPTH} bounces, GGX+Beckmann materials, {SPP_STEP} spp per step, "
-                            f"{K * SPP_STEP} spp per GPU ({spp_total}-sample Hammersley set), sample-pass sharding + one reduce",
+                "workload": f"cornellbox.glb {WIDTH}x{HEIGHT}, {DEPTH} bounces, GGX+Beckmann materials, {spp_step} spp per step, "
+                            f"{K * spp_step} spp per GPU ({spp_total}-sample Hammersley set), sample-pass sharding + one reduce",
                 "triangles": int(len(sc.array(rta.ARR_TRIS))),
                 "rays_closest": rays_c,
                 "rays_shadow": rays_s,
                 "rays_per_sample": rays / paths,
                 "bvh_build_s": t_build,
-                "frame_mean": float(frame.mean().item()) / (K * SPP_STEP * world),
+                "frame_mean": float(frame.mean().item()) / (K * spp_step * world),
             },
         }
         # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
