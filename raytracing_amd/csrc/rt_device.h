@@ -111,58 +111,110 @@ struct SceneView {
     int32_t fetch_chunk;   // rays a wave takes from its shard per cursor atomic (multiple of 64)
 };
 
-// Bounds::intersect, Math.h:755-770
-RT_DEV bool slab(const V3& bmin, const V3& bmax, const V3& o, const V3& inv, float& tnear_out) {
-    V3 t0 = (bmin - o) * inv;
-    V3 t1 = (bmax - o) * inv;
-    float ax = fmin_sel(t0.x, t1.x), ay = fmin_sel(t0.y, t1.y), az = fmin_sel(t0.z, t1.z);
-    float bx = fmax_sel(t0.x, t1.x), by = fmax_sel(t0.y, t1.y), bz = fmax_sel(t0.z, t1.z);
-    float tnear = fmax_sel(fmax_sel(ax, ay), az);
-    float tfar = fmin_sel(fmin_sel(bx, by), bz);
-    tnear_out = tnear;
-    return !(tnear > tfar || tfar < 0.f);
+// ---- device layout of a child-pair record (64 B, repacked from rt_bvh_pair by rt_scene_create) -------------------
+//   q0 = (lmin.x, lmin.y, lmax.x, lmax.y)   q1 = (rmin.x, rmin.y, rmax.x, rmax.y)
+//   q2 = (lmin.z, rmin.z, lmax.z, rmax.z)   q3 = (lref, rref, -, -)
+// so that the 24 subtract/multiply operations of the two slab tests are 6 v_pk_add_f32 + 6 v_pk_mul_f32 on aligned
+// register pairs (each IEEE per component: bit-identical to the scalar form).  A child ref >= 0 is the BYTE offset of
+// the child's own record (pair index * 64): it is the 32-bit offset operand of the load, no address arithmetic is left
+// on the vector ALU.  A child ref < 0 is a leaf, ~ref = its first triangle slot (as in rt_bvh_pair).
+#define RT_PAIR_BYTES 64
+#define RT_MAX_PAIRS ((int64_t)0x7fffffff / RT_PAIR_BYTES)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) f4 lds_cf4;
+typedef __attribute__((address_space(3))) int lds_int;
+
+RT_DEV float vmin(float a, float b) { // written as instructions: through fminf/fmaxf hipcc adds a canonicalising v_max_f32 x, x, x per operand
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RT_DEV float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RT_DEV float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+RT_DEV float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// A ray as the slab tests want it: origin and 1/dir (Math.h:756, true division) as register pairs.
+struct RaySlab {
+    f2 oxy, ozz, ixy, izz;
+};
+
+// Bounds::intersect (Math.h:755-770) on both children of a pair record.  EXACT = false: v_min_f32 / v_max3_f32 instead
+// of compare+select chains.  IEEE min/max differ from the reference's select forms (Math.h:17-24) only when an operand
+// is NaN (and in the sign of a zero result, which no comparison below can observe); a NaN needs 0 * inf, i.e. an
+// infinite 1/dir, or a non-finite origin.  The walks take this path only while every ray in the wave has finite origin
+// and finite 1/dir, so results are bit-identical.  EXACT = true: the select forms, in the reference's operand order.
+template <bool EXACT>
+RT_DEV void slab_pair(const f4& q0, const f4& q1, const f4& q2, const RaySlab& r, float& ln, bool& lh, float& rn, bool& rh) {
+    const f2 a = (f2{q0.x, q0.y} - r.oxy) * r.ixy; // left  t(min) x, y
+    const f2 b = (f2{q0.z, q0.w} - r.oxy) * r.ixy; // left  t(max) x, y
+    const f2 c = (f2{q1.x, q1.y} - r.oxy) * r.ixy; // right t(min) x, y
+    const f2 d = (f2{q1.z, q1.w} - r.oxy) * r.ixy; // right t(max) x, y
+    const f2 e = (f2{q2.x, q2.y} - r.ozz) * r.izz; // t(min) z of left, right
+    const f2 f = (f2{q2.z, q2.w} - r.ozz) * r.izz; // t(max) z of left, right
+    float lf, rf;
+    if (!EXACT) {
+        ln = vmax3(vmin(a.x, b.x), vmin(a.y, b.y), vmin(e.x, f.x));
+        lf = vmin3(vmax(a.x, b.x), vmax(a.y, b.y), vmax(e.x, f.x));
+        rn = vmax3(vmin(c.x, d.x), vmin(c.y, d.y), vmin(e.y, f.y));
+        rf = vmin3(vmax(c.x, d.x), vmax(c.y, d.y), vmax(e.y, f.y));
+    } else {
+        ln = fmax_sel(fmax_sel(fmin_sel(a.x, b.x), fmin_sel(a.y, b.y)), fmin_sel(e.x, f.x));
+        lf = fmin_sel(fmin_sel(fmax_sel(a.x, b.x), fmax_sel(a.y, b.y)), fmax_sel(e.x, f.x));
+        rn = fmax_sel(fmax_sel(fmin_sel(c.x, d.x), fmin_sel(c.y, d.y)), fmin_sel(e.y, f.y));
+        rf = fmin_sel(fmin_sel(fmax_sel(c.x, d.x), fmax_sel(c.y, d.y)), fmax_sel(e.y, f.y));
+    }
+    lh = !(ln > lf || lf < 0.f);
+    rh = !(rn > rf || rf < 0.f);
+}
+
+// One record: the top of the tree (every ray walks it) comes from LDS, which has its own bandwidth beside the vector
+// L1 that the divergent 64-byte record reads saturate; the rest through the 32-bit-offset form of the global load.
+RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_bytes, int cur, f4& q0, f4& q1, f4& q2, int& lref, int& rref) {
+    if (cur < top_bytes) {
+        lds_cf4* p = (lds_cf4*)((const __attribute__((address_space(3))) char*)top + cur);
+        q0 = p[0];
+        q1 = p[1];
+        q2 = p[2];
+        const f4 q3 = p[3];
+        lref = __float_as_int(q3.x);
+        rref = __float_as_int(q3.y);
+    } else {
+        const f4* p = (const f4*)((const char*)pairs + (uint32_t)cur);
+        q0 = p[0];
+        q1 = p[1];
+        q2 = p[2];
+        const f4 q3 = p[3];
+        lref = __float_as_int(q3.x);
+        rref = __float_as_int(q3.y);
+    }
 }
 
 #define RT_CUR_DONE ((int)0x80000000)   // lane has no ray
 #define RT_CUR_FINISH ((int)0x80000001) // lane's ray is complete, result not yet written
 
 struct RayState {
-    V3 o, d, inv;
+    V3 o, d;
     float tmax;  // shrinking upper bound on accepted t (Object.h:314)
     float t;     // best hit so far, INF before the first (Object.h:281)
     float u, v;
     int slot;    // best hit's triangle slot, -1 = none
-    bool exact;  // ray needs the select-form slab test (non-finite 1/dir or origin: NaNs possible)
     uint32_t q;  // queue position of this ray
 };
 
-// Same test with v_min_f32 / v_max3_f32 instead of compare+select chains (8 instructions instead of 20 selects with
-// VCC hazards).  IEEE min/max differ from the reference's select forms only when an operand is NaN (and in the sign of
-// a zero result, which no comparison below can observe); a NaN needs 0 * inf, i.e. an infinite 1/dir.  trace_queue takes
-// this path only while every lane stepping has a finite origin and finite 1/dir, so results are bit-identical.
-RT_DEV bool slab_fast(const V3& bmin, const V3& bmax, const V3& o, const V3& inv, float& tnear_out) {
-    V3 t0 = (bmin - o) * inv;
-    V3 t1 = (bmax - o) * inv;
-    // written as instructions: through fminf/fmaxf hipcc adds a canonicalising v_max_f32 x, x, x per operand
-    float ax, ay, az, bx, by, bz, tnear, tfar;
-    asm("v_min_f32 %0, %1, %2" : "=v"(ax) : "v"(t0.x), "v"(t1.x));
-    asm("v_min_f32 %0, %1, %2" : "=v"(ay) : "v"(t0.y), "v"(t1.y));
-    asm("v_min_f32 %0, %1, %2" : "=v"(az) : "v"(t0.z), "v"(t1.z));
-    asm("v_max_f32 %0, %1, %2" : "=v"(bx) : "v"(t0.x), "v"(t1.x));
-    asm("v_max_f32 %0, %1, %2" : "=v"(by) : "v"(t0.y), "v"(t1.y));
-    asm("v_max_f32 %0, %1, %2" : "=v"(bz) : "v"(t0.z), "v"(t1.z));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tnear) : "v"(ax), "v"(ay), "v"(az));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tfar) : "v"(bx), "v"(by), "v"(bz));
-    tnear_out = tnear;
-    return !(tnear > tfar || tfar < 0.f);
-}
-
-// Ray hand-out of the persistent traversal waves.  A queue is n_shards dense sub-queues (shard s = entries
-// [s*shard_cap, s*shard_cap + counts[s])) and every shard has its own fetch cursor; wave g works on shard g % n_shards
-// (the launch has a multiple of n_shards waves).  A wave with idle lanes takes the next `need` rays of its shard with
-// ONE atomic, so rays of a shard go to whichever of its waves has room: no wave is left holding a long static share
-// while others have finished.  One cursor for the whole queue would saturate (~88 same-address atomics/us on MI355X);
-// 64 shards keep every address far below that.  Rays handed to one wave are consecutive: the fetch is coalesced.
 // IntersectTriRay2 (Object.h:245-264, edges pre-differenced by the host) followed by the acceptance test of
 // TriangleMesh::intersect (Object.h:260, 309-315 with tmin = 0).  ONE definition for every caller (closest walk,
 // occlusion walk), so that both accept exactly the same (ray, triangle, tmax) triples.
@@ -188,6 +240,15 @@ RT_DEV bool tri_accept(const V3& o, const V3& d, const float4& a, const float4& 
     *v_out = v;
     return true;
 }
+// The three 16-byte parts of triangle slot `slot`, all requested before the first is used (one memory round trip per
+// leaf, not one for the edges and a second for v0 behind the determinant test).
+RT_DEV void load_tri(const float4* __restrict__ tris, int slot, float4& a, float4& b, float4& c) {
+    const float4* tp = (const float4*)((const char*)tris + (uint32_t)slot * 48u);
+    a = tp[0];
+    b = tp[1];
+    c = tp[2];
+    asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.x));
+}
 
 #ifdef RT_STATS // lane-occupancy instrumentation of the traversal loops (debug builds only: tools/lane_stats.sh)
 __device__ unsigned long long g_rt_stats[16];
@@ -200,6 +261,12 @@ __device__ unsigned long long g_rt_stats[16];
 #define RT_STAT_FLUSH(base)
 #endif
 
+// Ray hand-out of the persistent traversal waves.  A queue is n_shards dense sub-queues (shard s = entries
+// [s*shard_cap, s*shard_cap + counts[s])) and every shard has its own fetch cursor; wave g works on shard g % n_shards
+// (the launch has a multiple of n_shards waves).  A wave with idle lanes takes the next `need` rays of its shard with
+// ONE atomic, so rays of a shard go to whichever of its waves has room: no wave is left holding a long static share
+// while others have finished.  One cursor for the whole queue would saturate (~88 same-address atomics/us on MI355X);
+// 64 shards keep every address far below that.  Rays handed to one wave are consecutive: the fetch is coalesced.
 struct QueueShare {
     uint32_t base;     // first queue index of the shard
     uint32_t count;    // live rays in the shard
@@ -245,37 +312,52 @@ RT_DEV bool queue_fetch(QueueShare& qs, bool want, uint32_t* idx) {
     return got;
 }
 
-// Closest-hit (ANY = false: TriangleMesh::intersect, Object.h:273-344) or boolean occlusion (ANY = true:
-// trace_scene as used at main.cpp:250,281) over a dense ray queue, as PERSISTENT wave64s:
-//   * every wave refills its idle lanes from its own share of the queue, so lanes whose ray ended early do not idle
-//     until the slowest ray of their wave is done.  The share is static and interleaved — wave w of W owns the 64-ray
-//     groups w, w+W, w+2W, ... — so no atomic is needed (one shared cursor saturates at ~88 fetches/us on MI355X,
-//     which measured slower than no refill at all) and refills of whole groups stay coalesced;
-//   * "while-while" order: all lanes walk inner nodes until none has one pending, then all pending leaves are
-//     tested together — the two bodies are not interleaved per step under partial masks;
+// Origin and 1/dir of a fetched ray as register pairs; *exact = the ray needs the select-form slab test (non-finite
+// 1/dir or origin: NaNs possible; also true for NaN inputs).
+RT_DEV RaySlab ray_slab(const float4& o4, const float4& d4, bool* exact) {
+    const float ix = 1.f / d4.x, iy = 1.f / d4.y, iz = 1.f / d4.z; // Math.h:756
+    const float big = fmaxf(fmaxf(fabsf(ix), fabsf(iy)), fabsf(iz));
+    const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
+    *exact = !(big < INFINITY) || !(org < INFINITY);
+    RaySlab r;
+    r.oxy = f2{o4.x, o4.y};
+    r.ozz = f2{o4.z, o4.z};
+    r.ixy = f2{ix, iy};
+    r.izz = f2{iz, iz};
+    return r;
+}
+
+// Closest hit (TriangleMesh::intersect, Object.h:273-344) over a sharded ray queue, as PERSISTENT wave64s:
+//   * every wave refills its idle lanes from its shard of the queue (queue_fetch), so lanes whose ray ended early do
+//     not idle until the slowest ray of their wave is done;
+//   * "while-while" order: all lanes walk inner nodes until few have one pending, then the pending leaves are tested
+//     together — the two bodies are not interleaved per step under partial masks;
 //   * the traversal stack keeps its first RT_SHORT_STACK entries in LDS (column lds[entry * RT_TRAV_BLOCK]: lanes of a
 //     wave hit consecutive banks) and spills deeper entries to private memory, up to the reference's 64.
 // Per ray the visit order, the culling rule (`dist < t` at push time, not re-tested at pop), right-child-first on
 // ties and accept-on-equal-t are exactly the reference's, so results do not depend on how rays share a wave.
-// sink(ray state) is called once per ray when it completes (RayState::q = its global queue index).  Exit: a wave's private cursor only grows, so it stops
-// fetching once its next group starts past `count` and leaves the loop when its last lane finishes.
-template <bool ANY, class Sink>
+// sink(ray state) is called once per ray when it completes (RayState::q = its global queue index).  Exit: a shard's
+// cursor only grows, so a wave stops fetching once it has passed `count` and leaves the loop when its last lane is done.
+template <class Sink>
 RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                         const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
-                        int* lds, const float4* top, int n_top, Sink sink) {
+                        lds_int* lds, lds_cf4* top, int top_bytes, Sink sink) {
     int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
-    const uint32_t lane = __lane_id();
     RayState r;
     r.q = 0;
     r.slot = -1;
     r.t = INFINITY;
     r.tmax = INFINITY;
     r.u = r.v = 0.f;
-    r.o = r.d = r.inv = V3(0.f);
-    r.exact = false;
+    r.o = r.d = V3(0.f);
+    RaySlab rs;
+    rs.oxy = rs.ozz = rs.ixy = rs.izz = f2{0.f, 0.f};
+    bool exact = false;
     int cur = RT_CUR_DONE;
     int sp = 0;
     bool wave_exact = false; // wave-uniform: some lane holds a ray that needs the select-form slab test
+    const float4* __restrict__ pairs = sc.pairs;
+    const float4* __restrict__ tris = sc.tris;
     RT_STAT_DECL
     QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
@@ -286,51 +368,33 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 r.q = idx;
                 r.o = V3(o4);
                 r.d = V3(d4);
-                r.inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
-                {
-                    const float big = fmaxf(fmaxf(fabsf(r.inv.x), fabsf(r.inv.y)), fabsf(r.inv.z));
-                    const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
-                    r.exact = !(big < INFINITY) || !(org < INFINITY); // also true for NaNs
-                }
-                r.tmax = ANY ? o4.w : INFINITY;
+                rs = ray_slab(o4, d4, &exact);
+                r.tmax = INFINITY;
                 r.t = INFINITY;
                 r.slot = -1;
                 sp = 0;
                 cur = sc.root_ref;
             }
-            wave_exact = __ballot(r.exact && cur != RT_CUR_DONE) != 0ull;
+            wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
         }
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break; // nothing fetched: the queue is exhausted
         RT_STAT(3, cur != RT_CUR_DONE); // rounds, lanes holding a ray
 
         // ---- inner-node steps (Object.h:322-343): two per round, so the wave-level bookkeeping above and below is
-        // paid once per two node visits; written with selects and two short predicated blocks (push / pop)
+        // paid once per two node visits
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
             RT_STAT(0, cur >= 0); // inner steps
             if (cur >= 0) {
-                // the top of the tree (every ray walks it) comes from LDS, which has its own bandwidth beside the
-                // vector L1 that the divergent 64-byte record reads below saturate
-                float4 q0, q1, q2, q3;
-                if (cur < n_top) {
-                    const float4* p = top + 4 * cur;
-                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-                } else {
-                    const float4* p = sc.pairs + 4 * (size_t)cur;
-                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-                }
+                f4 q0, q1, q2;
+                int lref, rref;
+                load_pair(pairs, top, top_bytes, cur, q0, q1, q2, lref, rref);
                 float ld, rd;
                 bool lh, rh;
-                if (!wave_exact) {
-                    lh = slab_fast(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
-                    rh = slab_fast(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
-                } else {
-                    lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), r.o, r.inv, ld);
-                    rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), r.o, r.inv, rd);
-                }
+                if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
+                else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
                 lh = lh && ld < r.t;
                 rh = rh && rd < r.t;
-                const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                 const bool left_first = ld < rd; // ties visit the right child first (Object.h:329-336)
                 // next node when at least one child is hit: the nearer of two, else the one that is hit
                 cur = (lh && (!rh || left_first)) ? lref : rref;
@@ -344,7 +408,8 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                         cur = RT_CUR_FINISH;
                     } else {
                         sp--;
-                        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
+                        if (sp < RT_SHORT_STACK) cur = lds[sp * RT_TRAV_BLOCK];
+                        else cur = spill[sp - RT_SHORT_STACK];
                     }
                 }
             }
@@ -360,8 +425,8 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 bool last;
                 RT_STAT(1, true); // leaf turns
                 do {
-                    const float4* tp = sc.tris + 3 * (size_t)slot;
-                    const float4 a = tp[0], b = tp[1], c = tp[2];
+                    float4 a, b, c;
+                    load_tri(tris, slot, a, b, c);
                     last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
                     float tt, u, v;
                     if (tri_accept(r.o, r.d, a, b, c, r.tmax, &tt, &u, &v)) {
@@ -370,20 +435,21 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                         r.slot = slot;
                         r.u = u;
                         r.v = v;
-                        if (ANY) last = true;
                     }
                     slot++;
                 } while (!last);
-                if ((ANY && r.slot >= 0) || sp == 0) {
+                if (sp == 0) {
                     cur = RT_CUR_FINISH;
                 } else {
                     sp--;
-                    cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
+                    if (sp < RT_SHORT_STACK) cur = lds[sp * RT_TRAV_BLOCK];
+                    else cur = spill[sp - RT_SHORT_STACK];
                 }
             }
             if (cur == RT_CUR_FINISH) {
                 sink(r);
                 cur = RT_CUR_DONE;
+                exact = false;
             }
         }
     }
@@ -392,32 +458,38 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 
 #define RT_CUR_HIT ((int)0x80000002)    // occlusion_queue: an occluder was found
 #ifndef RT_PEND_CAP
-#define RT_PEND_CAP 8 // pending-leaf ring per lane in LDS (occlusion_queue); a power of two
+#define RT_PEND_CAP 8 // pending-leaf entries per lane in LDS (occlusion_queue)
 #endif
 #define RT_PEND_FULL_MAX (RT_PEND_CAP - 3) // a round of two inner steps adds at most 4 entries: it starts with <= CAP - 4
+#ifndef RT_OCC_STACK
+#define RT_OCC_STACK RT_SHORT_STACK // occlusion walk: stack entries per lane kept in LDS
+#endif
 
-// Boolean occlusion (trace_scene as used at main.cpp:250,281) over a dense ray queue.  The answer of the reference's
+// Boolean occlusion (trace_scene as used at main.cpp:250,281) over a sharded ray queue.  The answer of the reference's
 // any-hit walk does not depend on the order of its steps: its `t` stays infinite until the first accepted triangle
 // ends the walk, so a leaf is reached exactly when the box tests of all its ancestors pass, and the ray is occluded
 // exactly when some reached leaf holds a triangle that passes IntersectTriRay2 with 1e-4 < t <= tmax.  This walk
 // therefore evaluates the same tests on the same nodes but never lets a lane wait at a leaf: a child that is a leaf
 // and whose box is hit goes to a short per-lane pending list (LDS) and the lane carries on with inner nodes; the
-// pending triangles are tested together, oldest (nearest) first and one per lane and turn, once enough lanes hold one
-// (pend_min), a lane holds pend_full of them, or no lane has an inner node left.  Persistent waves, per-shard fetch
-// cursors and LDS/private stack as in trace_queue.  sink(queue index, occluded) is called once per ray.
+// pending triangles are tested together, one per lane and turn, once enough lanes hold one (pend_min), a lane holds
+// pend_full of them, or no lane has an inner node left.  Persistent waves, per-shard fetch cursors and LDS/private
+// stack as in trace_queue.  sink(queue index, tag = the ray's dir.w bits, occluded) is called once per ray.
 template <class Sink>
 RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                             const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
-                            int* lds, int* pend, const float4* top, int n_top, Sink sink) {
-    int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
-    const uint32_t lane = __lane_id();
-    V3 o(0.f), d(0.f), inv(0.f);
+                            lds_int* lds, lds_int* pend, lds_cf4* top, int top_bytes, Sink sink) {
+    int spill[RT_STACK_TOTAL - RT_OCC_STACK];
+    V3 o(0.f), d(0.f);
+    RaySlab rs;
+    rs.oxy = rs.ozz = rs.ixy = rs.izz = f2{0.f, 0.f};
     float tmax = 0.f;
-    uint32_t q = 0;
+    uint32_t q = 0, tag = 0;
     bool exact = false;
     bool wave_exact = false; // wave-uniform: some lane fetched a ray that needs the select-form slab test
     int cur = RT_CUR_DONE;
-    int sp = 0, np = 0, ph = 0; // stack depth; pending-leaf ring: count and head
+    int sp = 0, np = 0; // stack depth; pending leaves
+    const float4* __restrict__ pairs = sc.pairs;
+    const float4* __restrict__ tris = sc.tris;
     RT_STAT_DECL
     QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
@@ -426,19 +498,17 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
             if (queue_fetch(qs, cur == RT_CUR_DONE, &idx)) {
                 const float4 o4 = q_o[idx], d4 = q_d[idx];
                 q = idx;
+                tag = __float_as_uint(d4.w);
                 o = V3(o4);
                 d = V3(d4);
-                inv = V3(1.f / d4.x, 1.f / d4.y, 1.f / d4.z); // Math.h:756
-                const float big = fmaxf(fmaxf(fabsf(inv.x), fabsf(inv.y)), fabsf(inv.z));
-                const float org = fabsf(o4.x) + fabsf(o4.y) + fabsf(o4.z);
-                exact = !(big < INFINITY) || !(org < INFINITY);
+                rs = ray_slab(o4, d4, &exact);
                 tmax = o4.w;
                 sp = 0;
                 if (sc.root_ref >= 0) {
                     cur = sc.root_ref;
                     np = 0;
                 } else { // the whole mesh is one leaf; the root is never box-tested (Object.h:283-290)
-                    pend[(ph & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK] = sc.root_ref;
+                    pend[0] = sc.root_ref;
                     np = 1;
                     cur = RT_CUR_FINISH;
                 }
@@ -452,32 +522,21 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
         for (int rep = 0; rep < 2; rep++) {
             RT_STAT(0, cur >= 0);
             if (cur >= 0) {
-                float4 q0, q1, q2, q3;
-                if (cur < n_top) {
-                    const float4* p = top + 4 * cur;
-                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-                } else {
-                    const float4* p = sc.pairs + 4 * (size_t)cur;
-                    q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3];
-                }
+                f4 q0, q1, q2;
+                int lref, rref;
+                load_pair(pairs, top, top_bytes, cur, q0, q1, q2, lref, rref);
                 float ld, rd;
                 bool lh, rh;
-                if (!wave_exact) {
-                    lh = slab_fast(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), o, inv, ld);
-                    rh = slab_fast(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), o, inv, rd);
-                } else {
-                    lh = slab(V3(q0.x, q0.y, q0.z), V3(q0.w, q1.x, q1.y), o, inv, ld);
-                    rh = slab(V3(q1.z, q1.w, q2.x), V3(q2.y, q2.z, q2.w), o, inv, rd);
-                }
+                if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
+                else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
                 lh = lh && ld < INFINITY; // `dist < t` of Object.h:325-326 with t still infinite
                 rh = rh && rd < INFINITY;
-                const int lref = __float_as_int(q3.x), rref = __float_as_int(q3.y);
                 if (lh && lref < 0) {
-                    pend[((ph + np) & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK] = lref;
+                    pend[np * RT_TRAV_BLOCK] = lref;
                     np++;
                 }
                 if (rh && rref < 0) {
-                    pend[((ph + np) & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK] = rref;
+                    pend[np * RT_TRAV_BLOCK] = rref;
                     np++;
                 }
                 const bool li = lh && lref >= 0, ri = rh && rref >= 0;
@@ -485,15 +544,16 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 cur = (li && (!ri || left_first)) ? lref : rref;
                 if (li && ri) {
                     const int far = left_first ? rref : lref;
-                    if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = far;
-                    else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
+                    if (sp < RT_OCC_STACK) lds[sp * RT_TRAV_BLOCK] = far;
+                    else if (sp < RT_STACK_TOTAL) spill[sp - RT_OCC_STACK] = far;
                     sp++;
                 } else if (!li && !ri) {
                     if (sp == 0) {
                         cur = RT_CUR_FINISH;
                     } else {
                         sp--;
-                        cur = (sp < RT_SHORT_STACK) ? lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
+                        if (sp < RT_OCC_STACK) cur = lds[sp * RT_TRAV_BLOCK];
+                        else cur = spill[sp - RT_OCC_STACK];
                     }
                 }
             }
@@ -505,28 +565,27 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
         while (go) {
             RT_STAT(1, np > 0);
             if (np > 0) {
-                int slot = ~pend[(ph & (RT_PEND_CAP - 1)) * RT_TRAV_BLOCK];
-                ph++;
                 np--;
-                    bool last;
-                    do {
-                        const float4* tp = sc.tris + 3 * (size_t)slot;
-                        const float4 a = tp[0], b = tp[1], c = tp[2];
-                        last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
-                        float tt, u, v;
-                        if (tri_accept(o, d, a, b, c, tmax, &tt, &u, &v)) {
-                            cur = RT_CUR_HIT;
-                            np = 0;
-                            sp = 0;
-                            last = true;
-                        }
-                        slot++;
-                    } while (!last);
+                int slot = ~pend[np * RT_TRAV_BLOCK];
+                bool last;
+                do {
+                    float4 a, b, c;
+                    load_tri(tris, slot, a, b, c);
+                    last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
+                    float tt, u, v;
+                    if (tri_accept(o, d, a, b, c, tmax, &tt, &u, &v)) {
+                        cur = RT_CUR_HIT;
+                        np = 0;
+                        sp = 0;
+                        last = true;
+                    }
+                    slot++;
+                } while (!last);
             }
             go = __ballot(np >= sc.pend_full) != 0ull || (__ballot(cur >= 0) == 0ull && __ballot(np > 0) != 0ull);
         }
         if (cur == RT_CUR_HIT || (cur == RT_CUR_FINISH && np == 0)) {
-            sink(q, cur == RT_CUR_HIT);
+            sink(q, tag, cur == RT_CUR_HIT);
             cur = RT_CUR_DONE;
             exact = false;
         }

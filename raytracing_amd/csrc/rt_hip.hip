@@ -106,12 +106,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     }
 }
 
-// Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup) and returns how many there are.
+// Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup) and returns how many bytes that is.
 RT_DEV int stage_tree_top(const SceneView& sc, float4* s_top) {
     const int n_top = sc.n_pairs < RT_TOP_PAIRS ? sc.n_pairs : RT_TOP_PAIRS;
     for (int i = threadIdx.x; i < 4 * n_top; i += RT_TRAV_BLOCK) s_top[i] = sc.pairs[i];
     __syncthreads();
-    return n_top;
+    return n_top * RT_PAIR_BYTES;
 }
 
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const f
                                                       uint32_t n_shards, uint32_t shard_cap, float4* __restrict__ hit, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int n_top = stage_tree_top(sc, s_top);
-    trace_queue<false>(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, stack + threadIdx.x, s_top, n_top, [&](const RayState& r) {
+    const int top_bytes = stage_tree_top(sc, s_top);
+    trace_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes, [&](const RayState& r) {
         int slot = r.slot;
         if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
         hit[r.q] = make_float4(__int_as_float(slot), r.t, r.u, r.v);
@@ -131,24 +131,24 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const f
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
                                                      uint32_t n_shards, uint32_t shard_cap, uint8_t* __restrict__ vis) {
-    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ int stack[RT_OCC_STACK * RT_TRAV_BLOCK];
     __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int n_top = stage_tree_top(sc, s_top);
-    occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, stack + threadIdx.x, pend + threadIdx.x, s_top, n_top,
-                    [&](uint32_t q, bool occluded) { vis[__float_as_uint(s_d[q].w)] = occluded ? 0 : 1; });
+    const int top_bytes = stage_tree_top(sc, s_top);
+    occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
+                    top_bytes, [&](uint32_t, uint32_t target, bool occluded) { vis[target] = occluded ? 0 : 1; });
 }
 
 // Parity hook variant: rays + tmax in, occluded flag out (rt_trace_any).
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                   const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                   uint32_t shard_cap, uint8_t* __restrict__ occ) {
-    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ int stack[RT_OCC_STACK * RT_TRAV_BLOCK];
     __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int n_top = stage_tree_top(sc, s_top);
-    occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, stack + threadIdx.x, pend + threadIdx.x, s_top, n_top,
-                    [&](uint32_t q, bool occluded) { occ[q] = occluded ? 1 : 0; });
+    const int top_bytes = stage_tree_top(sc, s_top);
+    occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
+                    top_bytes, [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
 
 // wave64 compaction over the lanes that call it (under divergence: the lanes of the current branch): ONE atomic per
@@ -632,6 +632,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     *out = nullptr;
     if (d->n_tris <= 0 || !d->tris || !d->normals) return fail(RT_ERR_INVALID, "rt_scene_create: scene has no triangles");
     if (d->n_pairs < 0 || (d->n_pairs > 0 && !d->pairs)) return fail(RT_ERR_INVALID, "rt_scene_create: bad pair table");
+    if (d->n_pairs > RT_MAX_PAIRS) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^25 - 1 child-pair records");
+    if (d->n_tris > (int64_t)0xffffffffu / 48) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 89 million triangles");
     if (d->n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 15 area lights");
     if (d->n_materials <= 0 || !d->materials) return fail(RT_ERR_INVALID, "rt_scene_create: no materials");
     // every reference a kernel will follow is checked here, on the host, so that a bad
@@ -707,7 +709,21 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     const rt_bvh_pair* pairs;
     const rt_tri* tris;
     const rt_tri_normals* normals;
-    if ((rc = upload(s, d->pairs, (size_t)d->n_pairs, &pairs))) return bail(rc);
+    {
+        // device layout of the pair records (rt_device.h): bounds regrouped for packed arithmetic, inner refs as byte offsets
+        std::vector<rt_bvh_pair> dev((size_t)d->n_pairs);
+        auto ref = [](int32_t r) { return r >= 0 ? r * RT_PAIR_BYTES : r; };
+        for (int64_t i = 0; i < d->n_pairs; i++) {
+            const rt_bvh_pair& p = d->pairs[i];
+            float* f = (float*)&dev[(size_t)i];
+            const float q[12] = {p.lmin[0], p.lmin[1], p.lmax[0], p.lmax[1], p.rmin[0], p.rmin[1], p.rmax[0], p.rmax[1],
+                                 p.lmin[2], p.rmin[2], p.lmax[2], p.rmax[2]};
+            std::memcpy(f, q, sizeof(q));
+            const int32_t refs[4] = {ref(p.lref), ref(p.rref), 0, 0};
+            std::memcpy(f + 12, refs, sizeof(refs));
+        }
+        if ((rc = upload(s, dev.data(), (size_t)d->n_pairs, &pairs))) return bail(rc);
+    }
     if ((rc = upload(s, d->tris, (size_t)d->n_tris, &tris))) return bail(rc);
     if ((rc = upload(s, d->normals, (size_t)d->n_tris, &normals))) return bail(rc);
     if ((rc = upload(s, d->materials, (size_t)d->n_materials, &s->view.materials))) return bail(rc);
@@ -738,7 +754,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->view.pairs = (const float4*)pairs;
     s->view.tris = (const float4*)tris;
     s->view.normals = (const float4*)normals;
-    s->view.root_ref = d->root_ref;
+    s->view.root_ref = d->root_ref >= 0 ? d->root_ref * RT_PAIR_BYTES : d->root_ref;
     s->view.refill_min = 16;
     s->view.leaf_min = 16;
     s->view.pend_min = 48;
