@@ -462,8 +462,8 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 #endif
 #define RT_PEND_FULL_MAX (RT_PEND_CAP - 3) // a round of two inner steps adds at most 4 entries: it starts with <= CAP - 4
 #ifndef RT_OCC_STACK
-#define RT_OCC_STACK RT_SHORT_STACK // occlusion walk: stack entries per lane kept in LDS
-#endif
+#define RT_OCC_STACK 8 // occlusion walk: stack entries per lane kept in LDS.  With the pending list and the tree top a
+#endif                 // 256-thread workgroup holds 8 + 8 + 4 = 20 KB: eight of them fill a CU's 160 KB (12 entries: six)
 
 // Boolean occlusion (trace_scene as used at main.cpp:250,281) over a sharded ray queue.  The answer of the reference's
 // any-hit walk does not depend on the order of its steps: its `t` stays infinite until the first accepted triangle

@@ -758,7 +758,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->view.refill_min = 16;
     s->view.leaf_min = 16;
     s->view.pend_min = 48;
-    s->view.pend_full = 5;
+    s->view.pend_full = std::min(5, RT_PEND_FULL_MAX);
     s->view.wave_min_rays = 0;
     s->view.fetch_chunk = 128;
     if (const char* e = getenv("RT_TUNE_REFILL_MIN")) s->view.refill_min = std::max(1, atoi(e));
