@@ -15,18 +15,23 @@
 
 #define RT_BLOCK 256        // threads per workgroup = 4 wave64 (shading / streaming kernels)
 #ifndef RT_TRAV_BLOCK
-#define RT_TRAV_BLOCK 256
+#define RT_TRAV_BLOCK 1024
 #endif
 #ifndef RT_TOP_PAIRS
-#define RT_TOP_PAIRS 64
+#define RT_TOP_PAIRS 256
 #endif
-// RT_TRAV_BLOCK: threads per workgroup of the traversal kernels (measured: 256 beats 512 and 1024)
-// RT_TOP_PAIRS: child-pair records [0, RT_TOP_PAIRS) are read from LDS (4 KB per workgroup; measured: 64 beats 0 and 256);
-// the host numbers the top levels of the tree first
+// RT_TRAV_BLOCK: threads per workgroup of the traversal kernels.  RT_TOP_PAIRS: child-pair records [0, RT_TOP_PAIRS) are
+// read from LDS (16 KB per workgroup); the host numbers the top levels of the tree first.  On cornellbox half of all
+// node visits fall into the first 64 records.  Two 1024-thread workgroups fill a CU (32 waves) and each stages ONE copy
+// of the top for its 16 waves: measured 256 threads + 64 records 5.00, 512 + 128 5.07, 1024 + 256 5.15 Grays/s
+// (512 or 768 records: no further gain).
+#ifndef RT_OCC_TOP_PAIRS
+#define RT_OCC_TOP_PAIRS RT_TOP_PAIRS // tree top of the occlusion kernels
+#endif
 #ifndef RT_SHORT_STACK
-#define RT_SHORT_STACK 12
+#define RT_SHORT_STACK 8
 #endif
-// RT_SHORT_STACK: traversal stack entries per lane kept in LDS (12 KB per 256-thread workgroup)
+// RT_SHORT_STACK: traversal stack entries per lane kept in LDS (32 KB per 1024-thread workgroup)
 #define RT_STACK_TOTAL 64   // reference stack capacity (Object.h:275)
 
 // Queue counters and fetch cursors take atomics from every CU: each sits in its own 128-byte line (counter i at word
@@ -189,17 +194,27 @@ RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_by
         q0 = p[0];
         q1 = p[1];
         q2 = p[2];
-        const f4 q3 = p[3];
-        lref = __float_as_int(q3.x);
-        rref = __float_as_int(q3.y);
+        const unsigned long long rr = *(const __attribute__((address_space(3))) unsigned long long*)(p + 3); // ONE 8-byte read
+        lref = (int)(uint32_t)rr;
+        rref = (int)(uint32_t)(rr >> 32);
     } else {
         const f4* p = (const f4*)((const char*)pairs + (uint32_t)cur);
         q0 = p[0];
         q1 = p[1];
         q2 = p[2];
-        const f4 q3 = p[3];
-        lref = __float_as_int(q3.x);
-        rref = __float_as_int(q3.y);
+        const unsigned long long rr = *(const unsigned long long*)(p + 3); // 56 of the record's 64 bytes are read
+#ifdef RT_EXTRA_LOADS // experiment: redundant loads of the record's unused tail, to see what a load instruction costs
+        for (int xl = 0; xl < RT_EXTRA_LOADS; xl++) {
+#ifdef RT_EXTRA_COALESCED
+            const unsigned long long xx = *(const volatile unsigned long long*)((const char*)pairs + 8 * __lane_id());
+#else
+            const unsigned long long xx = *(const volatile unsigned long long*)((const char*)p + 56);
+#endif
+            asm volatile("" ::"v"(xx));
+        }
+#endif
+        lref = (int)(uint32_t)rr;
+        rref = (int)(uint32_t)(rr >> 32);
     }
 }
 
@@ -385,6 +400,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
             RT_STAT(0, cur >= 0); // inner steps
+            RT_STAT(2, cur >= 0 && cur < top_bytes); // ... of which read from LDS
             if (cur >= 0) {
                 f4 q0, q1, q2;
                 int lref, rref;
@@ -463,7 +479,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 #define RT_PEND_FULL_MAX (RT_PEND_CAP - 3) // a round of two inner steps adds at most 4 entries: it starts with <= CAP - 4
 #ifndef RT_OCC_STACK
 #define RT_OCC_STACK 8 // occlusion walk: stack entries per lane kept in LDS.  With the pending list and the tree top a
-#endif                 // 256-thread workgroup holds 8 + 8 + 4 = 20 KB: eight of them fill a CU's 160 KB (12 entries: six)
+#endif                 // 1024-thread workgroup holds 32 + 32 + 16 = 80 KB: two of them fill a CU's 160 KB
 
 // Boolean occlusion (trace_scene as used at main.cpp:250,281) over a sharded ray queue.  The answer of the reference's
 // any-hit walk does not depend on the order of its steps: its `t` stays infinite until the first accepted triangle
@@ -521,6 +537,7 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
 #pragma unroll
         for (int rep = 0; rep < 2; rep++) {
             RT_STAT(0, cur >= 0);
+            RT_STAT(2, cur >= 0 && cur < top_bytes);
             if (cur >= 0) {
                 f4 q0, q1, q2;
                 int lref, rref;
@@ -1116,8 +1133,32 @@ RT_DEV int imod(int a, int b) { // Math.h:44-47
     int r = a % b;
     return (r < 0) ? r + b : r;
 }
-RT_DEV V3 env_texel(const SceneView& sc, int x, int y) { return V3(sc.env_rgb + ((size_t)sc.env_w * y + x) * 3); }
-RT_DEV V3 env_lookup(const SceneView& sc, float u, float v) { // Image.h:46-64
+// The three sampling tables of the shading kernels (environment CDF, environment texels, emissive-triangle CDF), read
+// either from global memory or from the workgroup's LDS copy.  Two types, not one generic pointer: a generic pointer
+// turns every step of the CDF searches into a flat load that queues behind the kernel's divergent global traffic.
+typedef const __attribute__((address_space(3))) float lds_cfloat;
+struct GlobalTables {
+    const float* cdf;
+    const float* rgb;
+    const rt_emissive_tri* em;
+    RT_DEV float env_cdf(int i) const { return cdf[i]; }
+    RT_DEV V3 texel(int i) const { return V3(rgb + 3 * (size_t)i); }
+    RT_DEV float em_cdf(int i) const { return em[i].cdf; }
+    RT_DEV int em_slot(int i) const { return em[i].slot; }
+};
+struct LdsTables {
+    lds_cfloat* cdf;
+    lds_cfloat* rgb;
+    lds_cfloat* em; // rt_emissive_tri as two words: slot bits, cdf
+    RT_DEV float env_cdf(int i) const { return cdf[i]; }
+    RT_DEV V3 texel(int i) const { return V3(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]); }
+    RT_DEV float em_cdf(int i) const { return em[2 * i + 1]; }
+    RT_DEV int em_slot(int i) const { return __float_as_int(em[2 * i]); }
+};
+template <class TB>
+RT_DEV V3 env_texel(const SceneView& sc, const TB& tb, int x, int y) { return tb.texel(sc.env_w * y + x); }
+template <class TB>
+RT_DEV V3 env_lookup(const SceneView& sc, const TB& tb, float u, float v) { // Image.h:46-64
     const int w = sc.env_w, h = sc.env_h;
     u = u * w - 0.5f;
     v = v * h - 0.5f;
@@ -1128,7 +1169,7 @@ RT_DEV V3 env_lookup(const SceneView& sc, float u, float v) { // Image.h:46-64
     float ip;
     float uo = modff(u - ufi, &ip);
     float vo = modff(v - vfi, &ip);
-    V3 ff = env_texel(sc, ufi, vfi), fc = env_texel(sc, ufi, vci), cf = env_texel(sc, uci, vfi), cc = env_texel(sc, uci, vci);
+    V3 ff = env_texel(sc, tb, ufi, vfi), fc = env_texel(sc, tb, ufi, vci), cf = env_texel(sc, tb, uci, vfi), cc = env_texel(sc, tb, uci, vci);
     return (ff * (1.f - uo)) * (1.f - vo) + (fc * (1.f - uo)) * (vo) + (cf * (uo)) * (1.f - vo) + (cc * (uo)) * (vo);
 }
 RT_DEV float env_pdf_of(const SceneView& sc, const V3& color, float st) { // st = sin(theta)
@@ -1136,21 +1177,23 @@ RT_DEV float env_pdf_of(const SceneView& sc, const V3& color, float st) { // st 
     if (st == 0.f) return 0.f;
     return pdf * ((float)(sc.env_w * sc.env_h) / (2.f * kPi * kPi * st));
 }
-RT_DEV V3 env_eval(const SceneView& sc, const V3& dir, float* pdf) { // main.cpp:144-164
+template <class TB>
+RT_DEV V3 env_eval(const SceneView& sc, const TB& tb, const V3& dir, float* pdf) { // main.cpp:144-164
     float theta = acosf(dir.y);
     float phi = atan2f(dir.z, dir.x);
     float u = (kPi + phi) / kPi * 0.5f + sc.env_offset;
     float v = theta / kPi;
-    V3 color = env_lookup(sc, u, v);
+    V3 color = env_lookup(sc, tb, u, v);
     *pdf = env_pdf_of(sc, color, sinf(theta));
     return color;
 }
-RT_DEV V3 env_sample(const SceneView& sc, float rnd, V3* dir, float* pdf) { // main.cpp:121-143,165-184
+template <class TB>
+RT_DEV V3 env_sample(const SceneView& sc, const TB& tb, float rnd, V3* dir, float* pdf) { // main.cpp:121-143,165-184
     const int w = sc.env_w, h = sc.env_h;
     int lo = 0, hi = h - 1;
     while (lo < hi) {
         int mid = (lo + hi) / 2;
-        if (rnd < sc.env_cdf[(mid + 1) * w - 1]) hi = mid;
+        if (rnd < tb.env_cdf((mid + 1) * w - 1)) hi = mid;
         else lo = mid + 1;
     }
     const int y = lo;
@@ -1158,12 +1201,12 @@ RT_DEV V3 env_sample(const SceneView& sc, float rnd, V3* dir, float* pdf) { // m
     hi = w - 1;
     while (lo < hi) {
         int mid = (lo + hi) / 2;
-        if (rnd < sc.env_cdf[y * w + mid]) hi = mid;
+        if (rnd < tb.env_cdf(y * w + mid)) hi = mid;
         else lo = mid + 1;
     }
     const int x = lo;
     float ux = (float)x / w, uy = (float)y / h;
-    V3 color = env_lookup(sc, ux, uy);
+    V3 color = env_lookup(sc, tb, ux, uy);
     ux -= sc.env_offset;
     float phi = ux * 2.f * kPi;
     float theta = uy * kPi;
@@ -1177,7 +1220,8 @@ RT_DEV V3 env_sample(const SceneView& sc, float rnd, V3* dir, float* pdf) { // m
 
 // Instance::sample_geometry (Object.h:396-403) for a RECT light, area-CDF
 // triangle pick for a TRIMESH light (extension).
-RT_DEV void light_sample(const SceneView& sc, const rt_light& L, Rng& r, V3* point, V3* normal) {
+template <class TB>
+RT_DEV void light_sample(const SceneView& sc, const TB& tb, const rt_light& L, Rng& r, V3* point, V3* normal) {
     if (L.kind == RT_LIGHT_RECT) {
         float r1 = -1.f + 2.f * r.next(); // random_float(-1,1), Utils.h:12-15
         float r2 = -1.f + 2.f * r.next();
@@ -1197,10 +1241,10 @@ RT_DEV void light_sample(const SceneView& sc, const rt_light& L, Rng& r, V3* poi
     int lo = 0, hi = L.count - 1;
     while (lo < hi) {
         int mid = (lo + hi) / 2;
-        if (r0 < sc.emissive[L.first + mid].cdf) hi = mid;
+        if (r0 < tb.em_cdf(L.first + mid)) hi = mid;
         else lo = mid + 1;
     }
-    const int slot = sc.emissive[L.first + lo].slot;
+    const int slot = tb.em_slot(L.first + lo);
     const float4* tp = sc.tris + 3 * (size_t)slot;
     const float4* np = sc.normals + 3 * (size_t)slot;
     float su = sqrtf(b1);

@@ -52,10 +52,10 @@ struct Wave {
     float4* q_d[2];   // dir.xyz, unused
     float4* hit;      // slot (bits), t, u, v
     float4* q_T;      // throughput before this bounce's scatter (for NEE resolve)
-    // path state, indexed by path id
-    float4* T_pdf;    // throughput.xyz, scatter_pdf
-    float4* rad;      // radiance.xyz
-    float4* prev;     // prev.point.xyz, rng counter (bits)
+    // path state, indexed by path id: ONE 64-byte record per path (a queue entry's path id is random, so every access
+    // is its own HBM sector: three 16-byte arrays cost three sectors per read and three partial-line writes)
+    //   [0] throughput.xyz, scatter_pdf   [1] radiance.xyz, rng key (bits)   [2] prev.point.xyz, rng counter (bits)   [3] spare
+    float4* path;
     // NEE: K slots per queue position, slot k of queue entry q at [k*cap + q]
     float4* contrib;  // direct contribution of slot k (before throughput)
     uint8_t* vis;     // 1 = shadow ray unoccluded
@@ -97,9 +97,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     camera_ray(pp.cam, x, y, (uint32_t)(pp.spp_first + s_local), pp.spp_total, &o, &d);
     w.q_o[0][p] = pack(o, __int_as_float(p));
     w.q_d[0][p] = pack(d, 0.f);
-    w.T_pdf[p] = make_float4(1.f, 1.f, 1.f, 1.f);
-    w.rad[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    w.prev[p] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+    float4* ps = w.path + 4 * (size_t)p;
+    ps[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+    ps[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rng_key((uint32_t)(y * pp.width + x), (uint32_t)(pp.spp_first + s_local), pp.seed)));
+    ps[2] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
     if ((uint32_t)p < pp.n_shards) { // the dense camera-ray queue, cut into n_shards pieces for the traversal waves
         const int64_t left = (int64_t)pp.cap - (int64_t)p * pp.shard_cap;
         w.counts[(size_t)p * RT_CSTRIDE] = (uint32_t)(left < 0 ? 0 : (left > (int64_t)pp.shard_cap ? (int64_t)pp.shard_cap : left));
@@ -107,8 +108,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
 }
 
 // Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup) and returns how many bytes that is.
+template <int TOP>
 RT_DEV int stage_tree_top(const SceneView& sc, float4* s_top) {
-    const int n_top = sc.n_pairs < RT_TOP_PAIRS ? sc.n_pairs : RT_TOP_PAIRS;
+    const int n_top = sc.n_pairs < TOP ? sc.n_pairs : TOP;
     for (int i = threadIdx.x; i < 4 * n_top; i += RT_TRAV_BLOCK) s_top[i] = sc.pairs[i];
     __syncthreads();
     return n_top * RT_PAIR_BYTES;
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const f
                                                       uint32_t n_shards, uint32_t shard_cap, float4* __restrict__ hit, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top(sc, s_top);
+    const int top_bytes = stage_tree_top<RT_TOP_PAIRS>(sc, s_top);
     trace_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes, [&](const RayState& r) {
         int slot = r.slot;
         if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
@@ -133,8 +135,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const fl
                                                      uint32_t n_shards, uint32_t shard_cap, uint8_t* __restrict__ vis) {
     __shared__ int stack[RT_OCC_STACK * RT_TRAV_BLOCK];
     __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top(sc, s_top);
+    __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
+    const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
     occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
                     top_bytes, [&](uint32_t, uint32_t target, bool occluded) { vis[target] = occluded ? 0 : 1; });
 }
@@ -145,8 +147,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float
                                                   uint32_t shard_cap, uint8_t* __restrict__ occ) {
     __shared__ int stack[RT_OCC_STACK * RT_TRAV_BLOCK];
     __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top(sc, s_top);
+    __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
+    const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
     occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
                     top_bytes, [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
@@ -204,7 +206,8 @@ __device__ unsigned long long g_shade_stats[256 * 32];
 #define SH_MARK(i)
 #endif
 
-#define RT_LDS_CDF 2048 // sampling tables up to this many entries are staged in LDS (8 KB + 16 KB per workgroup)
+#define RT_LDS_CDF 2048 // emissive-triangle CDFs up to this many entries are staged in LDS (16 KB per workgroup)
+#define RT_LDS_ENV 1024 // environment maps up to this many texels are staged in LDS (4 KB CDF + 12 KB texels per workgroup)
 
 // One k_shade_t<KEY> launch per material type present in the scene (+ one for rays that left the scene): k_classify
 // sorts the bounce's queue entries by the type of the material they hit, so every wave of a shading kernel runs ONE
@@ -273,55 +276,54 @@ __global__ __launch_bounds__(RT_BLOCK) void k_classify(SceneView sc, Wave w, Pas
 
 // Shades queue entry q whose hit has material type KEY.  Runs under divergence; wave_reserve() compacts over the
 // lanes that reach it, which is all a dense queue needs.  The workgroup appends to output shard `out_shard`.
-template <int KEY>
-RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp, int bounce, int last_bounce, uint32_t q, uint32_t out_shard) {
+template <int KEY, class TB>
+RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const PassParams& pp, int bounce, int last_bounce, uint32_t q, uint32_t out_shard) {
     SH_T0
     const int in = bounce & 1, out = in ^ 1;
     const float4 o4 = w.q_o[in][q], d4 = w.q_d[in][q], h4 = w.hit[q];
     const int p = __float_as_int(o4.w);
     const V3 ro(o4), rd(d4);
     const int slot = __float_as_int(h4.x);
-    const float4 tp = w.T_pdf[p];
+    float4* ps = w.path + 4 * (size_t)p;
+    const float4 tp = ps[0], rk = ps[1];
     V3 T(tp);
     const float scatter_pdf = tp.w;
-    V3 rad(w.rad[p]);
+    V3 rad(rk);
     float4 nee_T = make_float4(0.f, 0.f, 0.f, 0.f); // .w = 1 when this entry has NEE slots to resolve
     SH_MARK(0); // queue + path state loads
 
     if (KEY == RT_KEY_MISS) { // main.cpp:340-359
         if (pp.has_env) {
             float env_pdf;
-            V3 bg = env_eval(sc, rd, &env_pdf);
+            V3 bg = env_eval(sc, tb, rd, &env_pdf);
             float mw = 1.f;
             if (bounce > 0) mw = power_heuristic(scatter_pdf, env_pdf);
             rad = rad + (T * bg) * mw;
-            w.rad[p] = pack(rad, 0.f);
+            ps[1] = pack(rad, rk.w);
         }
         w.q_T[q] = nee_T;
         SH_MARK(1); // miss: environment lookup
         return;
     }
     // TriangleMesh::intersect tail, Object.h:350-355
-    const float4* tq = sc.tris + 3 * (size_t)slot;
+    // the device copy of the normals record carries the triangle's material and light index in its pad words, so
+    // shading reads one 48-byte record per hit (every divergent load instruction costs 64 L1 look-ups)
     const float4* nq = sc.normals + 3 * (size_t)slot;
-    const int mat_id = __float_as_int(tq[1].w), light_id = __float_as_int(tq[2].w);
+    const float4 n0 = nq[0], n1 = nq[1], n2 = nq[2];
+    const int mat_id = __float_as_int(n0.w), light_id = __float_as_int(n1.w);
     Surf si;
     si.point = ro + rd * h4.y;
-    V3 N = (1.f - h4.z - h4.w) * V3(nq[0]) + h4.z * V3(nq[1]) + h4.w * V3(nq[2]);
+    V3 N = (1.f - h4.z - h4.w) * V3(n0) + h4.z * V3(n1) + h4.w * V3(n2);
     N = normalize(N);
     si.front_face = dot(rd, N) < 0.f;
     si.normal = si.front_face ? N : -N;
     rt_material mat = sc.materials[mat_id];
     mat.type = KEY; // compile-time constant: the material switches below fold to this kernel's one case
 
-    const float4 pv = w.prev[p];
+    const float4 pv = ps[2];
     Rng rng;
-    {
-        const int s_local = p / pp.npix, pix = p - s_local * pp.npix;
-        const int x = pp.x0 + pix % pp.tw, y = pp.y0 + pix / pp.tw;
-        rng.key = rng_key((uint32_t)(y * pp.width + x), (uint32_t)(pp.spp_first + s_local), pp.seed);
-        rng.ctr = __float_as_uint(pv.w);
-    }
+    rng.key = __float_as_uint(rk.w); // rng_key(pixel, sample, seed), stored by k_generate
+    rng.ctr = __float_as_uint(pv.w);
 
     const V3 emitted = mat_emitted(mat);
     float weight = 1.f;
@@ -337,7 +339,7 @@ RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp,
         }
     }
     rad = rad + (weight * emitted) * T;
-    w.rad[p] = pack(rad, 0.f);
+    ps[1] = pack(rad, rk.w);
     SH_MARK(2); // surface, material fetch, emission
 
     Scatter scat = mat_sample(mat, si, rd, rng);
@@ -354,7 +356,7 @@ RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp,
     bool want_env = false;
     if (pp.has_env) {
         float env_pdf;
-        V3 col = env_sample(sc, rng.next(), &env_dir, &env_pdf);
+        V3 col = env_sample(sc, tb, rng.next(), &env_dir, &env_pdf);
         want_env = dot(env_dir, si.normal) > 0.f;
         if (want_env) {
             float bp;
@@ -362,8 +364,7 @@ RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp,
             float mis = power_heuristic(env_pdf, bp);
             env_c = ((mis * f) * col) / env_pdf;
         }
-        w.contrib[q] = pack(env_c, 0.f);
-        w.vis[q] = 0;
+        w.contrib[q] = pack(env_c, 0.f); // without a shadow ray the slot's vis byte is stale, and its contribution an exact zero
     }
     SH_MARK(4); // environment NEE
     // one reservation for all of this wave's shadow rays: [env ray] + one per light, contiguous per lane
@@ -379,9 +380,9 @@ RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp,
         k = 1;
     }
     for (int i = 0; i < sc.n_lights; i++, k++, j++) {
-        const rt_light& L = sc.lights[i];
+        const rt_light& L = sc.lights[__builtin_amdgcn_readfirstlane(i)]; // wave-uniform: read through the scalar cache
         V3 point, normal;
-        light_sample(sc, L, rng, &point, &normal);
+        light_sample(sc, tb, L, rng, &point, &normal);
         V3 ld = point - si.point;
         float length = len(ld);
         ld = ld / length;
@@ -399,16 +400,15 @@ RT_DEV void shade_item(const SceneView& sc, const Wave& w, const PassParams& pp,
         const uint32_t target = (uint32_t)k * pp.capq + q;
         w.s_o[j] = pack(sh_origin, length - 0.001f);
         w.s_d[j] = pack(ld, __uint_as_float(target));
-        w.contrib[target] = pack(c, 0.f);
-        w.vis[target] = 0;
+        w.contrib[target] = pack(c, 0.f); // k_shadow writes vis[target] for every queued ray
     }
     SH_MARK(5); // light NEE
     nee_T = pack(T, 1.f);
     w.q_T[q] = nee_T;
 
     T = (T * scat.f) / scat.pdf; // main.cpp:434
-    w.T_pdf[p] = pack(T, scat.pdf);
-    w.prev[p] = pack(si.point, __uint_as_float(rng.ctr));
+    ps[0] = pack(T, scat.pdf);
+    ps[2] = pack(si.point, __uint_as_float(rng.ctr));
     if (!last_bounce) { // next-bounce ray queue, compacted over the surviving lanes
         const uint32_t qi = out_shard * pp.shard_cap + wave_reserve(1u, false, &w.counts[(size_t)((uint32_t)(bounce + 1) * pp.n_shards + out_shard) * RT_CSTRIDE]);
         w.q_o[out][qi] = pack(scat.origin, __int_as_float(p));
@@ -428,22 +428,22 @@ struct ShadeOrder { // the shading kernels of a bounce in launch order
 #endif
 template <int KEY>
 __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView sc_in, Wave w, PassParams pp, ShadeOrder order, int bounce, int last_bounce) {
-    // The two sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox); from LDS a step
-    // costs ~100 cycles instead of an L2 round trip.
-    __shared__ float s_env_cdf[RT_LDS_CDF];
-    __shared__ rt_emissive_tri s_emissive[RT_LDS_CDF];
+    // The sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox) and the environment is read
+    // with four bilinear taps: from LDS when all the tables fit (wave-uniform choice between two instantiations).
+    __shared__ float s_env_cdf[RT_LDS_ENV];
+    __shared__ float s_env_rgb[RT_LDS_ENV * 3];
+    __shared__ float s_emissive[RT_LDS_CDF * 2];
     const uint32_t n = w.type_counts[(size_t)(bounce * 16 + KEY) * RT_CSTRIDE];
     if (blockIdx.x * RT_BLOCK >= n) return; // uniform: fewer entries than resident workgroups
-    SceneView sc = sc_in;
-    if (KEY != RT_KEY_MISS && KEY != RT_MAT_EMISSIVE) { // those two never reach next-event estimation
-        const int n_env = sc_in.env_cdf ? sc_in.env_w * sc_in.env_h : 0;
-        if (n_env > 0 && n_env <= RT_LDS_CDF) {
-            for (int i = threadIdx.x; i < n_env; i += RT_BLOCK) s_env_cdf[i] = sc_in.env_cdf[i];
-            sc.env_cdf = s_env_cdf;
-        }
-        if (sc_in.n_emissive > 0 && sc_in.n_emissive <= RT_LDS_CDF) {
-            for (int i = threadIdx.x; i < sc_in.n_emissive; i += RT_BLOCK) s_emissive[i] = sc_in.emissive[i];
-            sc.emissive = s_emissive;
+    const SceneView& sc = sc_in;
+    const int n_env = sc.env_cdf ? sc.env_w * sc.env_h : 0;
+    const bool staged = n_env <= RT_LDS_ENV && sc.n_emissive <= RT_LDS_CDF;
+    if (staged && KEY != RT_MAT_EMISSIVE) { // (emitters never reach next-event estimation and are never missed)
+        for (int i = threadIdx.x; i < 3 * n_env; i += RT_BLOCK) s_env_rgb[i] = sc.env_rgb[i];
+        if (KEY != RT_KEY_MISS) {
+            for (int i = threadIdx.x; i < n_env; i += RT_BLOCK) s_env_cdf[i] = sc.env_cdf[i];
+            const float* em = (const float*)sc.emissive;
+            for (int i = threadIdx.x; i < 2 * sc.n_emissive; i += RT_BLOCK) s_emissive[i] = em[i];
         }
         __syncthreads();
     }
@@ -455,10 +455,26 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView 
     for (int k = 0; k < order.n && order.keys[k] != KEY; k++)
         group0 += (w.type_counts[(size_t)(bounce * 16 + order.keys[k]) * RT_CSTRIDE] + RT_BLOCK - 1) / RT_BLOCK;
     const uint32_t* perm = w.perm + (size_t)KEY * pp.capq;
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) { // persistent, grid-stride
-        const uint32_t i = base + threadIdx.x;
-        const uint32_t out_shard = (group0 + base / RT_BLOCK) % pp.n_shards;
-        if (i < n) shade_item<KEY>(sc, w, pp, bounce, last_bounce, perm[i], out_shard);
+    if (staged) {
+        LdsTables tb;
+        tb.cdf = (lds_cfloat*)s_env_cdf;
+        tb.rgb = (lds_cfloat*)s_env_rgb;
+        tb.em = (lds_cfloat*)s_emissive;
+        for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) { // persistent, grid-stride
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t out_shard = (group0 + base / RT_BLOCK) % pp.n_shards;
+            if (i < n) shade_item<KEY>(sc, tb, w, pp, bounce, last_bounce, perm[i], out_shard);
+        }
+    } else {
+        GlobalTables tb;
+        tb.cdf = sc.env_cdf;
+        tb.rgb = sc.env_rgb;
+        tb.em = sc.emissive;
+        for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+            const uint32_t i = base + threadIdx.x;
+            const uint32_t out_shard = (group0 + base / RT_BLOCK) % pp.n_shards;
+            if (i < n) shade_item<KEY>(sc, tb, w, pp, bounce, last_bounce, perm[i], out_shard);
+        }
     }
 }
 
@@ -474,9 +490,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp,
     for (int k = 0; k < pp.K; k++)
         if (w.vis[(size_t)k * pp.capq + q]) direct = direct + V3(w.contrib[(size_t)k * pp.capq + q]);
     const int p = __float_as_int(w.q_o[in][q].w);
-    V3 rad(w.rad[p]);
+    float4* pr = w.path + 4 * (size_t)p + 1;
+    const float4 rk = *pr;
+    V3 rad(rk);
     rad = rad + V3(T4) * direct;
-    w.rad[p] = pack(rad, 0.f);
+    *pr = pack(rad, rk.w);
 }
 
 // pixel_total += s with the NaN guard of main.cpp:984-987, samples in index order
@@ -488,7 +506,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(Wave w, PassParams pp, 
     float* px = sum + ((size_t)y * pp.width + x) * 3;
     V3 total(px[0], px[1], px[2]);
     for (int s = 0; s < pp.spp_pass; s++) {
-        V3 v(w.rad[(size_t)s * pp.npix + pix]);
+        V3 v(w.path[4 * ((size_t)s * pp.npix + pix) + 1]);
         if (v.x != v.x) v = V3(0.f);
         total = total + v;
     }
@@ -582,9 +600,7 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
     }
     if ((rc = wave_alloc(s, &w.hit, c))) return rc;
     if ((rc = wave_alloc(s, &w.q_T, c))) return rc;
-    if ((rc = wave_alloc(s, &w.T_pdf, c))) return rc;
-    if ((rc = wave_alloc(s, &w.rad, c))) return rc;
-    if ((rc = wave_alloc(s, &w.prev, c))) return rc;
+    if ((rc = wave_alloc(s, &w.path, 4 * c))) return rc;
     if ((rc = wave_alloc(s, &w.contrib, kc))) return rc;
     if ((rc = wave_alloc(s, &w.vis, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_o, kc))) return rc;
@@ -681,7 +697,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
             const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK; // workgroups per RT_SHARDS waves
             s->persistent_blocks = std::max(wg_unit, ((unsigned)prop.multiProcessorCount * (2048u / RT_TRAV_BLOCK)) / wg_unit * wg_unit);
-            s->shade_blocks = std::max((unsigned)RT_SHARDS, ((unsigned)prop.multiProcessorCount * 4u) / RT_SHARDS * RT_SHARDS);
+            unsigned shade_mult = 4; // resident shading workgroups per CU
+            if (const char* e = getenv("RT_TUNE_SHADE_MULT")) shade_mult = (unsigned)std::max(1, std::min(8, atoi(e)));
+            s->shade_blocks = std::max((unsigned)RT_SHARDS, ((unsigned)prop.multiProcessorCount * shade_mult) / RT_SHARDS * RT_SHARDS);
             if (const char* e = getenv("RT_TUNE_PERSIST_EIGHTHS")) // traversal grid as eighths of full occupancy
                 s->persistent_blocks = std::max(wg_unit, s->persistent_blocks * (unsigned)std::max(1, std::min(8, atoi(e))) / 8u / wg_unit * wg_unit);
             // several passes in flight: each pass's traversal launches take 3/8 of the wave slots, so the other pass's
@@ -725,7 +743,14 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if ((rc = upload(s, dev.data(), (size_t)d->n_pairs, &pairs))) return bail(rc);
     }
     if ((rc = upload(s, d->tris, (size_t)d->n_tris, &tris))) return bail(rc);
-    if ((rc = upload(s, d->normals, (size_t)d->n_tris, &normals))) return bail(rc);
+    {
+        std::vector<rt_tri_normals> dev(d->normals, d->normals + d->n_tris);
+        for (int64_t i = 0; i < d->n_tris; i++) { // pad words of the device copy: the triangle's material and light index
+            std::memcpy(&dev[(size_t)i].pad0, &d->tris[i].material, 4);
+            std::memcpy(&dev[(size_t)i].pad1, &d->tris[i].light, 4);
+        }
+        if ((rc = upload(s, dev.data(), (size_t)d->n_tris, &normals))) return bail(rc);
+    }
     if ((rc = upload(s, d->materials, (size_t)d->n_materials, &s->view.materials))) return bail(rc);
     if ((rc = upload(s, d->lights, (size_t)d->n_lights, &s->view.lights))) return bail(rc);
     if ((rc = upload(s, d->emissive_tris, (size_t)d->n_emissive_tris, &s->view.emissive))) return bail(rc);

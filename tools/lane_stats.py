@@ -23,9 +23,10 @@ _, st = sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=4, spp_
 assert lib.rt_debug_lane_stats(buf) == 0
 v = list(buf)
 for name, base, rays in (("closest", 0, st["rays_closest"]), ("occlusion", 8, st["rays_shadow"])):
-    inner_w, inner_l, leaf_w, leaf_l, _, _, rounds, held = v[base:base + 8]
+    inner_w, inner_l, leaf_w, leaf_l, _, top_l, rounds, held = v[base:base + 8]
     print(f"{name}: rays {rays}  rounds {rounds} (lanes holding a ray {held / max(rounds, 1):.1f})")
     print(f"  inner steps: {inner_w} wave-steps, {inner_l / max(inner_w, 1):.1f} lanes each, {inner_l / rays:.2f} per ray")
+    print(f"  inner steps read from the LDS tree top: {100.0 * top_l / max(inner_l, 1):.1f} %")
     print(f"  leaf turns : {leaf_w} wave-turns, {leaf_l / max(leaf_w, 1):.1f} lanes each, {leaf_l / rays:.2f} per ray")
 
 sbuf = (C.c_ulonglong * 32)()
