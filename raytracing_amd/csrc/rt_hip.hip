@@ -289,7 +289,7 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
     V3 T(tp);
     const float scatter_pdf = tp.w;
     V3 rad(rk);
-    float4 nee_T = make_float4(0.f, 0.f, 0.f, 0.f); // .w = 1 when this entry has NEE slots to resolve
+    float4 nee_T = make_float4(0.f, 0.f, 0.f, 0.f); // .w = path id + 1 (bits) when this entry has NEE slots to resolve, else 0
     SH_MARK(0); // queue + path state loads
 
     if (KEY == RT_KEY_MISS) { // main.cpp:340-359
@@ -403,7 +403,7 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
         w.contrib[target] = pack(c, 0.f); // k_shadow writes vis[target] for every queued ray
     }
     SH_MARK(5); // light NEE
-    nee_T = pack(T, 1.f);
+    nee_T = pack(T, __int_as_float(p + 1));
     w.q_T[q] = nee_T;
 
     T = (T * scat.f) / scat.pdf; // main.cpp:434
@@ -480,16 +480,15 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView 
 
 // radiance += throughput * direct (main.cpp:430), slots summed in reference order
 __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp, int bounce) {
-    const int in = bounce & 1;
     const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
     bool block_idle;
     if (!queue_entry_live(w, pp, bounce, q, &block_idle)) return;
     const float4 T4 = w.q_T[q];
-    if (T4.w == 0.f) return;
+    const int p = __float_as_int(T4.w) - 1; // (the ray queue entry need not be read for the path id)
+    if (p < 0) return;
     V3 direct(0.f);
     for (int k = 0; k < pp.K; k++)
         if (w.vis[(size_t)k * pp.capq + q]) direct = direct + V3(w.contrib[(size_t)k * pp.capq + q]);
-    const int p = __float_as_int(w.q_o[in][q].w);
     float4* pr = w.path + 4 * (size_t)p + 1;
     const float4 rk = *pr;
     V3 rad(rk);
