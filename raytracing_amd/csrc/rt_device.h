@@ -387,6 +387,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 r.tmax = INFINITY;
                 r.t = INFINITY;
                 r.slot = -1;
+                r.u = r.v = 0.f; // a miss reports (-1, inf, 0, 0), not the lane's previous hit
                 sp = 0;
                 cur = sc.root_ref;
             }
