@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["cornellbox", "random1m"], default="cornellbox",
+                    help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow rays only")
     args = ap.parse_args()
 
     import numpy as np
@@ -89,11 +91,22 @@ def main():
 
     # ---- scene: load, build the BVH on the host, flatten, upload once
     t0 = time.time()
-    sc = scenes.cornellbox(rta)
-    sc.build()
+    depth = DEPTH
+    visits_json = VISITS_JSON
+    if args.workload == "cornellbox":
+        sc = scenes.cornellbox(rta)
+        sc.build()
+        cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
+        label = "cornellbox.glb"
+    else:  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
+        sc = scenes.random_triangles(rta, 1_000_000)
+        sc.build()  # the reference's SAH builder: ~40 s
+        cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
+        depth = 1
+        visits_json = os.path.join(ROOT, "profiles", "visits_random1m_1080p_d1.json")
+        label = "1M random triangles (seed 1234), one rectangle light"
     t_build = time.time() - t0
     sc.upload(local_rank)
-    cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
 
     K, W = args.steps, args.warmup
     spp_step = args.spp_step
@@ -101,7 +114,7 @@ def main():
     frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
     def step(i, timing):
-        _, st = sc.render(cam, WIDTH, HEIGHT, spp=spp_step, max_depth=DEPTH, seed=1, spp_begin=first + (i % K) * spp_step,
+        _, st = sc.render(cam, WIDTH, HEIGHT, spp=spp_step, max_depth=depth, seed=1, spp_begin=first + (i % K) * spp_step,
                           spp_total=spp_total, spp_per_pass=args.spp_per_pass, device_out=frame.data_ptr(), timing=timing)
         return st
 
@@ -154,7 +167,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"cornellbox.glb {WIDTH}x{HEIGHT}, {DEPTH} bounces, GGX+Beckmann materials, {spp_step} spp per step, "
+                "workload": f"{label} {WIDTH}x{HEIGHT}, {depth} bounces, " + ("GGX+Beckmann materials, " if args.workload == "cornellbox" else "") + f"{spp_step} spp per step, "
                             f"{K * spp_step} spp per GPU ({spp_total}-sample Hammersley set), sample-pass sharding + one reduce",
                 "triangles": int(len(sc.array(rta.ARR_TRIS))),
                 "rays_closest": rays_c,
@@ -165,7 +178,7 @@ def main():
             },
         }
         # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
-        visits = json.load(open(VISITS_JSON)) if os.path.exists(VISITS_JSON) else None
+        visits = json.load(open(visits_json)) if os.path.exists(visits_json) else None
         kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"
         if visits:
             v = visits["closest" if kern == "k_closest" else "shadow"]
@@ -174,7 +187,7 @@ def main():
             launches = stats["launches_closest"] if kern == "k_closest" else stats["launches_shadow"]
             gbps = n_rays * v["bytes_per_ray"] / (ms * 1e-3) / 1e9
             traffic = None
-            if os.path.exists(PMC_JSON):
+            if os.path.exists(PMC_JSON) and args.workload == "cornellbox":
                 pmc = json.load(open(PMC_JSON)).get(kern, {})
                 if pmc.get("dispatches") and "hbm_read_bytes_corrected" in pmc and "hbm_write_bytes" in pmc:
                     traffic = (pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]) / pmc["dispatches"]
@@ -184,7 +197,7 @@ def main():
                 "avg_launch_ms": ms / max(launches, 1), "launches": launches,
             }
         out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.workload == "cornellbox":
             out["cpu_baseline"] = cpu_baseline(scenes, rta, sc)
         print(json.dumps(out), flush=True)
     if world > 1:

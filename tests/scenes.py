@@ -93,6 +93,11 @@ def random_triangles(rta, n, seed=1234, material=None):
     return sc
 
 
+def random_triangles_camera(rta, width, height):
+    """Config 3 view: the unit box of random_triangles() seen from +z."""
+    return rta.camera(rta.look_at((0.5, 0.5, 2.6), (0.5, 0.5, 0.5), (0, 1, 0)), 39.6, width, height)
+
+
 def cornellbox(rta, mode=None, emissive_scale=15.0, env=0.02):
     """cornellbox.glb (data asset of the reference, committed under tests/golden/) through Scene::load_from_gltf.
     mode: a raytracing_amd GLTF_* material mode (default GLTF_GGX: the BASELINE config-2 GGX + Beckmann mix)."""

@@ -16,11 +16,22 @@ import oracle_bindings as orc  # noqa: E402
 import raytracing_amd as rta  # noqa: E402
 import scenes  # noqa: E402
 
-W, H, SPP, DEPTH = 480, 270, 8, 8
-sc = scenes.cornellbox(rta)
-sc.build()
+WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "cornellbox"
+if WORKLOAD == "cornellbox":
+    W, H, SPP, DEPTH = 480, 270, 8, 8
+    sc = scenes.cornellbox(rta)
+    sc.build()
+    cam = scenes.cornell_camera(rta, sc, W, H)
+    label = f"cornellbox.glb GGX+Beckmann, depth {DEPTH}, camera of the file"
+    name = "visits_cornellbox_1080p_d8.json"
+else:  # BASELINE config 3: 1 000 000 random triangles, primary + shadow rays only (depth 1); the SAH build takes ~40 s
+    W, H, SPP, DEPTH = 480, 270, 2, 1
+    sc = scenes.random_triangles(rta, 1_000_000)
+    sc.build()
+    cam = scenes.random_triangles_camera(rta, W, H)
+    label = "1 000 000 random triangles in the unit box (seed 1234), one rectangle light, depth 1"
+    name = "visits_random1m_1080p_d1.json"
 osc = orc.scene_from_host(sc)
-cam = scenes.cornell_camera(rta, sc, W, H)
 _, c = orc.render(osc, cam, W, H, SPP, DEPTH, seed=1, spp_total=1024)
 
 
@@ -30,12 +41,12 @@ def entry(inner, leaf, rays):
 
 
 out = {
-    "workload": f"cornellbox.glb GGX+Beckmann, depth {DEPTH}, camera of the file, sampled at {W}x{H} x {SPP} spp by the oracle",
+    "workload": f"{label}, sampled at {W}x{H} x {SPP} spp by the oracle",
     "formula": "bytes_per_ray = 64*inner + 52*leaf + 48",
     "closest": entry(c["inner_visits"], c["leaf_visits"], c["rays_closest"]),
     "shadow": entry(c["shadow_inner_visits"], c["shadow_leaf_visits"], c["rays_shadow"]),
     "rays_per_sample": (c["rays_closest"] + c["rays_shadow"]) / c["paths"],
 }
-path = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
+path = os.path.join(ROOT, "profiles", name)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
