@@ -84,10 +84,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if rta.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # RT_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend — exercises the N > 1 control path (windows, barriers,
+    # max-over-ranks timing, the frame reduce through a host copy) on a one-GPU box; its numbers mean nothing
+    rehearse = bool(os.environ.get("RT_BENCH_REHEARSE"))
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- scene: load, build the BVH on the host, flatten, upload once
     t0 = time.time()
@@ -134,7 +142,12 @@ def main():
         else:
             for k in st:
                 stats[k] += st[k]
-    sharding.reduce_frame(frame, dst=0)  # the frame's single RCCL reduce over xGMI (no-op at world 1)
+    if rehearse and world > 1:
+        host = frame.cpu()
+        sharding.reduce_frame(host, dst=0)
+        frame.copy_(host)
+    else:
+        sharding.reduce_frame(frame, dst=0)  # the frame's single RCCL reduce over xGMI (no-op at world 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -142,7 +155,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     totals = torch.tensor([elapsed, float(stats["rays_closest"]), float(stats["rays_shadow"]), float(stats["paths"])],
-                          dtype=torch.float64, device=f"cuda:{local_rank}")
+                          dtype=torch.float64, device="cpu" if rehearse else f"cuda:{local_rank}")
     if world > 1:
         tmax = totals[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
