@@ -106,6 +106,8 @@ def load_libraries():
     host.rth_scene_free.argtypes = [vp]
     host.rth_scene_load_gltf.argtypes = [vp, C.c_char_p, i32, f32]
     host.rth_scene_add_mesh.argtypes = [vp, vp, i64, vp, i64]
+    host.rth_scene_add_instance.argtypes = [vp, vp, i64, vp, i64, vp, i32]
+    host.rth_scene_add_instance.restype = None
     host.rth_scene_add_material.argtypes = [vp, vp]
     host.rth_scene_set_material.argtypes = [vp, i32, vp]
     host.rth_scene_add_rect_light.argtypes = [vp, vp, f32, f32, vp, vp]
@@ -228,6 +230,14 @@ class Scene:
         if len(tris) and int(tris["idx"].max()) >= len(verts):
             raise ValueError("triangle index out of range")
         self._host.rth_scene_add_mesh(self._h, _ptr(verts), len(verts), _ptr(tris), len(tris))
+
+    def add_instance(self, verts, tris, transform16, material=-1):
+        """Scene::add_instance: the mesh placed with a column-major model-to-world matrix, flattened into the merged mesh."""
+        verts = np.ascontiguousarray(verts, dtype=VERTEX)
+        tris = np.ascontiguousarray(tris, dtype=TRIANGLE)
+        if len(tris) and int(tris["idx"].max()) >= len(verts):
+            raise ValueError("triangle index out of range")
+        self._host.rth_scene_add_instance(self._h, _ptr(verts), len(verts), _ptr(tris), len(tris), _ptr(_f32(transform16, 16)), int(material))
 
     def add_material(self, rec):
         rec = np.ascontiguousarray(rec, dtype=MATERIAL)

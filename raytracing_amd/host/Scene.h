@@ -144,6 +144,12 @@ public:
     // two emissive triangles into sceneMergedMesh + the sampled light.
     void add_rectangle_light(vec3 normal, float u_length, float v_length, vec3 emit, const mat4& transform);
     void set_environment(HDRImage* img, float degrees_offset = 0.f); // takes ownership
+    // Instance(TriangleMesh, material, transform) of the legacy design (Object.h:364-423, main.cpp:456-470), flattened
+    // at scene set-up: the mesh's triangles enter sceneMergedMesh in world space — positions through
+    // Transform::to_world_point, normals through normalize(to_world_normal) exactly as Instance::intersect reports
+    // them (Object.h:388-391) — so the GPU walks ONE tree (BASELINE config 5: "instanced mesh, flattened at upload").
+    // material_override >= 0 replaces every triangle's materialIndex.
+    void add_instance(const Mesh& mesh, const mat4& model_to_world, int material_override = -1);
 
     // stages of build_top_level_bvh, exposed for tests and for hosts without a GPU
     void build_acceleration(int max_per_leaf = 1, PartitionStrategy strat = BVH_SAH);

@@ -52,6 +52,17 @@ void rth_scene_add_mesh(rth_scene* s, const void* verts, int64_t n_verts, const 
     }
 }
 
+// Scene::add_instance: the mesh (same layouts as rth_scene_add_mesh) placed with a column-major model-to-world matrix.
+void rth_scene_add_instance(rth_scene* s, const void* verts, int64_t n_verts, const void* tris, int64_t n_tris, const float* transform16,
+                            int32_t material_override) {
+    Mesh m;
+    const Vertex* v = (const Vertex*)verts;
+    const MeshTriangle* t = (const MeshTriangle*)tris;
+    m.verts.assign(v, v + n_verts);
+    m.triangles.assign(t, t + n_tris);
+    s->scene.add_instance(m, mat4::from_columns(transform16), material_override);
+}
+
 int32_t rth_scene_add_material(rth_scene* s, const rt_material* rec) {
     Material* m = material_from_record(*rec);
     if (!m) return -1;

@@ -93,6 +93,56 @@ def random_triangles(rta, n, seed=1234, material=None):
     return sc
 
 
+def uv_sphere(rta, n_lat, n_lon, material=0):
+    """Indexed unit sphere: 2 * n_lon * (n_lat - 1) triangles, smooth normals."""
+    th = np.linspace(0.0, np.pi, n_lat + 1)[1:-1]
+    ph = np.linspace(0.0, 2.0 * np.pi, n_lon, endpoint=False)
+    ring = np.stack([np.outer(np.sin(th), np.cos(ph)), np.outer(np.cos(th), np.ones_like(ph)), np.outer(np.sin(th), np.sin(ph))], -1)
+    pos = np.concatenate([[[0.0, 1.0, 0.0]], ring.reshape(-1, 3), [[0.0, -1.0, 0.0]]]).astype(np.float32)
+    v = np.zeros(len(pos), rta.VERTEX)
+    v["pos"] = pos
+    v["normal"] = pos
+    idx = []
+    r = lambda i, j: 1 + i * n_lon + (j % n_lon)
+    for j in range(n_lon):
+        idx.append((0, r(0, j + 1), r(0, j)))
+        idx.append((len(pos) - 1, r(n_lat - 2, j), r(n_lat - 2, j + 1)))
+    for i in range(n_lat - 2):
+        for j in range(n_lon):
+            idx.append((r(i, j), r(i, j + 1), r(i + 1, j + 1)))
+            idx.append((r(i, j), r(i + 1, j + 1), r(i + 1, j)))
+    t = np.zeros(len(idx), rta.TRIANGLE)
+    t["idx"] = np.asarray(idx, np.uint32)
+    t["material"] = material
+    return v, t
+
+
+def instance_transforms(copies, seed=99, lo=(-1.4, 0.3, -1.4), hi=(1.4, 3.0, 1.4), scale=(0.04, 0.12)):
+    """Column-major model-to-world matrices: random rotation, uniform scale in `scale`, translation in the box."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(copies):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        m = np.eye(4)
+        m[:3, :3] = q * rng.uniform(*scale)
+        m[:3, 3] = np.asarray(lo) + rng.random(3) * (np.asarray(hi) - np.asarray(lo))
+        out.append(m.T.reshape(-1).astype(np.float32))
+    return out
+
+
+def cornell_with_instances(rta, n_lat, n_lon, copies, seed=99):
+    """BASELINE config 5 in shape: cornellbox.glb plus ONE mesh (a UV sphere of 2 n_lon (n_lat - 1) triangles) instanced
+    `copies` times inside the room (100 000 triangles x 50 = the configuration's 5 M), flattened at scene set-up."""
+    sc = cornellbox(rta)
+    mat = sc.add_material(rta.material(rta.MAT_GGX, s=(0.35, 0.0)))
+    v, t = uv_sphere(rta, n_lat, n_lon)
+    for m in instance_transforms(copies, seed):
+        sc.add_instance(v, t, m, material=mat)
+    return sc
+
+
 def random_triangles_camera(rta, width, height):
     """Config 3 view: the unit box of random_triangles() seen from +z."""
     return rta.camera(rta.look_at((0.5, 0.5, 2.6), (0.5, 0.5, 0.5), (0, 1, 0)), 39.6, width, height)

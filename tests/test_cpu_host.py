@@ -193,3 +193,33 @@ def test_sharding_helpers():
     assert (cover == 1).all()
     with pytest.raises(ValueError):
         sharding.sample_window(4, 4, 1)
+
+
+def test_add_instance_flattens_with_the_reference_transform(rta):
+    """Scene::add_instance = Instance(TriangleMesh, material, transform) flattened: positions through the matrix,
+    normals through the normalised inverse transpose (Object.h:388-391); identity = add_mesh."""
+    v, t = scenes.uv_sphere(rta, 6, 8)
+    a, b = rta.Scene(), rta.Scene()
+    for s in (a, b):
+        s.add_material(rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5)))
+    a.add_mesh(v, t)
+    b.add_instance(v, t, np.eye(4, dtype=np.float32).reshape(-1))
+    av, bv = a.array(rta.ARR_VERTS), b.array(rta.ARR_VERTS)
+    assert np.array_equal(av["pos"], bv["pos"]) and np.allclose(av["normal"], bv["normal"], atol=1e-6)  # (normals are re-normalised)
+    assert np.array_equal(a.array(rta.ARR_TRIS), b.array(rta.ARR_TRIS))
+    m = np.array([[0.0, -2.0, 0.0, 1.0], [0.5, 0.0, 0.0, 2.0], [0.0, 0.0, 3.0, -1.0], [0, 0, 0, 1]], np.float64)  # rotation x non-uniform scale + translation
+    c = rta.Scene()
+    mid = c.add_material(rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5)))
+    c.add_material(rta.material(rta.MAT_GGX, s=(0.3, 0.0)))
+    c.add_mesh(v, t)
+    c.add_instance(v, t, m.T.reshape(-1).astype(np.float32), material=1)
+    cv, ct = c.array(rta.ARR_VERTS), c.array(rta.ARR_TRIS)
+    assert len(cv) == 2 * len(v) and len(ct) == 2 * len(t)
+    want = (m[:3, :3] @ v["pos"].astype(np.float64).T).T + m[:3, 3]
+    assert np.allclose(cv["pos"][len(v):], want, rtol=1e-6, atol=1e-6)
+    nn = (np.linalg.inv(m[:3, :3]).T @ v["normal"].astype(np.float64).T).T
+    nn /= np.linalg.norm(nn, axis=1, keepdims=True)
+    assert np.allclose(cv["normal"][len(v):], nn, atol=1e-5)
+    assert np.array_equal(ct["idx"][len(t):], t["idx"] + len(v)) and (ct["material"][len(t):] == 1).all() and (ct["material"][:len(t)] == mid).all()
+    c.build()
+    assert c.info()["root_ref"] >= 0

@@ -82,3 +82,49 @@ def test_random_triangles_1m_properties(rta, gpu):
         else:
             assert abs(hits["t"][i] - t) <= 1e-5 * t, (i, hits[i], tri, t)
             assert hits["tri"][i] == tri or abs(hits["t"][i] - t) <= 1e-6 * t
+
+
+def test_cornell_with_instances_bit_parity(rta, orc, gpu):
+    """BASELINE config 5 in small: cornellbox + one mesh instanced 12 times (flattened at set-up): hits, occlusion and a
+    small image against the oracle."""
+    sc = scenes.cornell_with_instances(rta, 12, 16, 12)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.scene_from_host(sc)
+    cam = scenes.cornell_camera(rta, sc, 96, 54)
+    rays = np.concatenate([orc.camera_rays(cam, 96, 54, 0, 2), scenes.random_rays(20_000, 51, lo=(-1.7, 0, -1.7), hi=(1.7, 3.4, 1.7))])
+    got = sc.trace_closest(rays)
+    want, _ = orc.closest_hit(osc, rays)
+    assert np.array_equal(got["tri"], want["tri"])
+    hit = want["tri"] >= 0
+    n_cornell = 13170
+    assert (want["tri"][hit] >= n_cornell).mean() > 0.005  # the instances are in view
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][hit], want[f][hit]), f
+    tmax = np.full(len(rays), np.inf, np.float32)
+    assert np.array_equal(sc.trace_any(rays, tmax), orc.any_hit(osc, rays, tmax))
+    img, _ = sc.render(cam, 96, 54, spp=8, max_depth=8, seed=3)
+    ref, _ = orc.render(osc, cam, 96, 54, 8, 8, seed=3)
+    rel = float(np.sqrt(np.mean((img - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+    assert rel < 1e-3, rel
+
+
+def test_instanced_5m_properties(rta, gpu):
+    """The configuration's full size: 100 352-triangle mesh x 50 instances + cornellbox = 5.03 M triangles (BVH_MIDDLE
+    tree), checked through occlusion <=> closest hit and batch-order independence."""
+    sc = scenes.cornell_with_instances(rta, 225, 224, 50)
+    n = len(sc.array(rta.ARR_TRIS))
+    assert n == 13170 + 50 * 2 * 224 * 224
+    sc.build(max_per_leaf=1, strategy=0)
+    sc.upload(gpu)
+    rays = scenes.random_rays(300_000, 52, lo=(-1.7, 0, -1.7), hi=(1.7, 3.4, 1.7))
+    hits = sc.trace_closest(rays)
+    hit = hits["tri"] >= 0
+    assert hit.mean() > 0.8 and (hits["tri"][hit] < n).all() and (hits["tri"][hit] >= 13170).mean() > 0.005
+    inf = np.full(len(rays), np.inf, np.float32)
+    assert np.array_equal(sc.trace_any(rays, inf).astype(bool), hit)
+    tm = np.where(hit, hits["t"], 1.0).astype(np.float32)
+    assert sc.trace_any(rays, tm).astype(bool)[hit].all() and not sc.trace_any(rays, (0.5 * tm).astype(np.float32)).astype(bool)[hit].any()
+    perm = np.random.default_rng(53).permutation(len(rays))
+    again = sc.trace_closest(rays[perm])
+    assert np.array_equal(again.view(np.uint8), hits[perm].view(np.uint8))
