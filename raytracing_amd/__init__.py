@@ -107,6 +107,10 @@ def load_libraries():
     host.rth_scene_load_gltf.argtypes = [vp, C.c_char_p, i32, f32]
     host.rth_scene_add_mesh.argtypes = [vp, vp, i64, vp, i64]
     host.rth_scene_add_instance.argtypes = [vp, vp, i64, vp, i64, vp, i32]
+    host.rth_scene_load_env_hdr.argtypes = [vp, C.c_char_p, f32]
+    host.rth_scene_load_env_hdr.restype = i32
+    host.rth_scene_get_env.argtypes = [vp, vp, vp]
+    host.rth_scene_get_env.restype = i32
     host.rth_scene_add_instance.restype = None
     host.rth_scene_add_material.argtypes = [vp, vp]
     host.rth_scene_set_material.argtypes = [vp, i32, vp]
@@ -262,6 +266,19 @@ class Scene:
         rgb = _f32(rgb)
         h, w, _ = rgb.shape
         self._host.rth_scene_set_env(self._h, w, h, _ptr(rgb), degrees_offset)
+
+    def load_env_hdr(self, path, degrees_offset=0.0):
+        """load_hdr (Radiance .hdr) + environment light; False (and a message on stdout) when the file cannot be read."""
+        return bool(self._host.rth_scene_load_env_hdr(self._h, os.fsencode(path), degrees_offset))
+
+    def env(self):
+        """The environment image the scene holds, (h, w, 3) float32, or None."""
+        dims = np.zeros(2, np.int32)
+        if not self._host.rth_scene_get_env(self._h, _ptr(dims), None):
+            return None
+        rgb = np.zeros((int(dims[1]), int(dims[0]), 3), np.float32)
+        self._host.rth_scene_get_env(self._h, _ptr(dims), _ptr(rgb))
+        return rgb
 
     def build(self, max_per_leaf=1, strategy=1):
         self._host.rth_scene_build(self._h, max_per_leaf, strategy)

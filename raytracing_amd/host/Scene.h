@@ -68,6 +68,7 @@ public:
 };
 using HDRImage = Image;
 HDRImage* make_uniform_environment(int width, int height, vec3 radiance);
+HDRImage* load_hdr(const std::string& filename); // Image.cpp:6-30: Radiance RGBE -> RGB_32f, nullptr + message on failure
 
 class Geometry { // Object.h:9-24
 public:

@@ -84,6 +84,24 @@ void rth_scene_add_rect_light(rth_scene* s, const float* normal3, float u_length
                                  mat4::from_columns(transform16));
 }
 
+// load_hdr + EnviormentLight set-up as main.cpp:1028-1036 does: 1 = loaded, 0 = the file could not be read.
+int32_t rth_scene_load_env_hdr(rth_scene* s, const char* path, float degrees_offset) {
+    HDRImage* img = load_hdr(path);
+    if (!img) return 0;
+    s->scene.set_environment(img, degrees_offset);
+    return 1;
+}
+
+// the environment image as the scene holds it: dims2 = {w, h}; rgb (w*h*3 floats) may be NULL to query the size
+int32_t rth_scene_get_env(rth_scene* s, int32_t* dims2, float* rgb) {
+    const HDRImage* img = s->scene.environment;
+    if (!img) return 0;
+    dims2[0] = img->width;
+    dims2[1] = img->height;
+    if (rgb) std::memcpy(rgb, img->imageData.data(), (size_t)img->width * img->height * 3 * sizeof(float));
+    return 1;
+}
+
 // RGB_32f lat-long environment (copied).  rgb == NULL removes it.
 void rth_scene_set_env(rth_scene* s, int32_t w, int32_t h, const float* rgb, float degrees_offset) {
     if (!rgb) {
