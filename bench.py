@@ -121,9 +121,10 @@ def main():
     first, _, spp_total = sharding.sample_window(rank, world, K * spp_step)  # this rank's window of the Hammersley set
     frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
 
-    def step(i, timing):
+    def step(i, timing, serial=False, target=None):
         _, st = sc.render(cam, WIDTH, HEIGHT, spp=spp_step, max_depth=depth, seed=1, spp_begin=first + (i % K) * spp_step,
-                          spp_total=spp_total, spp_per_pass=args.spp_per_pass, device_out=frame.data_ptr(), timing=timing)
+                          spp_total=spp_total, spp_per_pass=args.spp_per_pass, device_out=(target if target is not None else frame).data_ptr(),
+                          timing=timing, serial=serial)
         return st
 
     for i in range(W):
@@ -209,6 +210,19 @@ def main():
                 "traffic": traffic, "algorithmic_bytes_per_launch": n_rays * v["bytes_per_ray"] / max(launches, 1), "kernel": kern, "bytes_per_ray": v["bytes_per_ray"], "rays_per_launch": n_rays / max(launches, 1),
                 "avg_launch_ms": ms / max(launches, 1), "launches": launches,
             }
+            # the same kernel alone on the GPU: one untimed step with one sample pass at a time (RT_RENDER_SERIAL).  In the
+            # timed region up to four passes share the GPU, so a launch's event-bracketed duration includes its neighbours' work.
+            scratch = torch.zeros_like(frame)
+            step(0, True, serial=True, target=scratch)
+            alone = step(1 % K, True, serial=True, target=scratch)
+            a_rays = alone["rays_closest"] if kern == "k_closest" else alone["rays_shadow"]
+            a_ms = alone["ms_closest"] if kern == "k_closest" else alone["ms_shadow"]
+            a_n = alone["launches_closest"] if kern == "k_closest" else alone["launches_shadow"]
+            a_gbps = a_rays * v["bytes_per_ray"] / (a_ms * 1e-3) / 1e9
+            out["roofline"]["standalone"] = {"achieved": a_gbps, "frac": a_gbps / HBM_PEAK_GBPS, "avg_launch_ms": a_ms / max(a_n, 1),
+                                             "launches": a_n, "ms_per_step": alone["ms_total"],
+                                             "note": "untimed extra step, one pass at a time; the tree is L2/LDS-resident on cornellbox, so "
+                                                     "algorithmic bytes are not HBM bytes (see traffic)"}
         out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
         if not args.no_cpu_baseline and world == 1 and args.workload == "cornellbox":
             out["cpu_baseline"] = cpu_baseline(scenes, rta, sc)

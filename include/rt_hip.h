@@ -185,6 +185,7 @@ typedef struct rt_camera {
 #define RT_RENDER_CLEAR 1u      /* zero radiance_sum before accumulating      */
 #define RT_RENDER_DEVICE_OUT 2u /* radiance_sum is a device pointer           */
 #define RT_RENDER_TIMING 4u     /* bracket every kernel with HIP events       */
+#define RT_RENDER_SERIAL 8u     /* one sample pass at a time on one stream (per-kernel times then are stand-alone times) */
 
 /* Options (main.cpp:836-850) + the sample window this call renders.
  * Sample i of pixel (x,y) is hammersley_2d(i, spp_total) (Utils.h:148-151);

@@ -40,7 +40,7 @@ MAT_MATTE, MAT_GGX, MAT_BECKMANN, MAT_EMISSIVE, MAT_DISNEY_DIFFUSE, MAT_DISNEY_M
 MAT_DISNEY_CLEARCOAT, MAT_DISNEY_GLASS, MAT_ROUGH_DIELECTRIC, MAT_DISNEY_SHEEN, MAT_DISNEY_UBER, MAT_GLASS = 6, 7, 8, 9, 10, 11
 GLTF_UBER, GLTF_MATTE, GLTF_GGX = 0, 1, 2
 FILTER_GAUSSIAN, FILTER_BOX = 0, 1
-RENDER_CLEAR, RENDER_DEVICE_OUT, RENDER_TIMING = 1, 2, 4
+RENDER_CLEAR, RENDER_DEVICE_OUT, RENDER_TIMING, RENDER_SERIAL = 1, 2, 4, 8
 
 (ARR_VERTS, ARR_TRIS, ARR_NODES, ARR_INDICES, ARR_MATERIALS, ARR_LIGHTS, ARR_EMISSIVE, ARR_TRI_LIGHT, ARR_ENV_RGB,
  ARR_ENV_CDF, ARR_FLAT_PAIRS, ARR_FLAT_TRIS, ARR_FLAT_NORMALS, ARR_EMISSIVE_ORIG) = range(14)
@@ -333,7 +333,7 @@ class Scene:
         return occ
 
     def render(self, cam, width, height, spp, max_depth, seed=0, spp_begin=0, spp_total=None, tile=None,
-               spp_per_pass=0, out=None, device_out=None, timing=False, clear=None):
+               spp_per_pass=0, out=None, device_out=None, timing=False, clear=None, serial=False):
         """rt_render.  Returns (radiance_sum [H,W,3] fp32 or None with device_out, stats dict)."""
         opt = RtOptions()
         opt.width, opt.height = width, height
@@ -343,7 +343,7 @@ class Scene:
         opt.x0, opt.y0, opt.x1, opt.y1 = tile if tile is not None else (0, 0, width, height)
         opt.seed = seed
         opt.spp_per_pass = spp_per_pass
-        flags = RENDER_TIMING if timing else 0
+        flags = (RENDER_TIMING if timing else 0) | (RENDER_SERIAL if serial else 0)
         stats = RtStats()
         if device_out is not None:
             flags |= RENDER_DEVICE_OUT

@@ -932,7 +932,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     const int n_pass = (o->spp_count + spp_pass - 1) / spp_pass;
     // Sample passes are independent until their sums are added to the frame: with two or more, pass i runs on
     // stream i % sets with its own buffer set, and only the accumulation kernels are ordered (pass order, by events).
-    const int sets = getenv("RT_TUNE_ONE_STREAM") ? 1 : std::min(n_pass, s->max_sets);
+    const int sets = (getenv("RT_TUNE_ONE_STREAM") || (o->flags & RT_RENDER_SERIAL)) ? 1 : std::min(n_pass, s->max_sets);
     int rc;
     if ((rc = ensure_wave(s, capq, K, sets))) return rc;
     if (s->h_counts_n < (size_t)n_pass * RT_COUNTS) {
