@@ -230,12 +230,16 @@ struct MeshHit {
 
 // TriangleMesh::intersect traversal, Object.h:273-344.  any = stop at the first
 // accepted hit (boolean use of trace_scene, main.cpp:250,281).
+// cull_tmax is NOT the reference: it restates the one place where the product's occlusion walk leaves the reference's
+// procedure (boxes entered beyond the segment's end are skipped) and exists only so that
+// tools/measure_visits.py can count the nodes THAT walk visits.  Every parity check runs with cull_tmax = false.
 inline bool mesh_traverse(const orc_scene* s, const V3& o, const V3& d, float tmin, float tmax, bool any, MeshHit& out,
-                          orc_visits* vis) {
+                          orc_visits* vis, bool cull_tmax = false) {
     int stack[64];
     stack[0] = 0;
     int sp = 1;
     float t = INFINITY;
+    const float segment_end = (tmax > 0.f && tmax < INFINITY) ? tmax * 1.0001f + 0.000001f : (tmax <= 0.f ? tmax : INFINITY);
     int inner = 0, leaf = 0;
     while (sp > 0) {
         const orc_node* nd = &s->nodes[stack[--sp]];
@@ -271,6 +275,10 @@ inline bool mesh_traverse(const orc_scene* s, const V3& o, const V3& d, float tm
         bool rh = slab(R->bmin, R->bmax, o, d, rd);
         lh = lh && ld < t;
         rh = rh && rd < t;
+        if (any && cull_tmax) {
+            lh = lh && ld < segment_end;
+            rh = rh && rd < segment_end;
+        }
         if (lh && rh) {
             if (ld < rd) {
                 stack[sp++] = nd->left_node + 1;
@@ -990,11 +998,13 @@ struct Ctx {
     uint64_t rays_closest = 0, rays_shadow = 0, inner = 0, leaf = 0, s_inner = 0, s_leaf = 0;
 };
 
+bool g_count_product_occlusion_walk = false; // orc_count_product_occlusion_walk(): visit statistics only
+
 bool occluded(Ctx& c, const V3& o, const V3& d, float tmin, float tmax) {
     c.rays_shadow++;
     MeshHit h;
     orc_visits vis;
-    bool hit = mesh_traverse(c.s, o, d, tmin, tmax, true, h, &vis);
+    bool hit = mesh_traverse(c.s, o, d, tmin, tmax, true, h, &vis, g_count_product_occlusion_walk);
     c.s_inner += vis.inner;
     c.s_leaf += vis.leaf;
     return hit;
@@ -1310,6 +1320,8 @@ int32_t orc_material_sample(const orc_material* m, const float* point3, const fl
 
 uint32_t orc_rng_key(uint32_t pixel, uint32_t sample, uint32_t seed) { return rng_key(pixel, sample, seed); }
 float orc_rng_draw(uint32_t key, uint32_t counter) { return rng_float(key, counter); }
+
+void orc_count_product_occlusion_walk(int32_t on) { g_count_product_occlusion_walk = on != 0; }
 
 void orc_radiance(const orc_scene* s, const orc_camera* cam, const orc_options* o, int32_t x, int32_t y, int32_t i,
                   float* rgb3, orc_counters* c) {

@@ -160,6 +160,11 @@ int32_t orc_material_sample(const orc_material* m, const float* point3, const fl
 uint32_t orc_rng_key(uint32_t pixel, uint32_t sample, uint32_t seed);
 float orc_rng_draw(uint32_t key, uint32_t counter);
 
+/* Visit statistics only (tools/measure_visits.py): when on, shadow rays of orc_render / orc_radiance skip boxes entered
+ * beyond the segment's end, as the product's occlusion walk does, so that the inner/leaf counters describe THAT walk.
+ * Off by default; orc_any_hit and every parity test always use the reference's procedure (Object.h:322-326). */
+void orc_count_product_occlusion_walk(int32_t on);
+
 /* get_ray_color (main.cpp:325-441) for sample i of pixel (x, y). */
 void orc_radiance(const orc_scene* s, const orc_camera* cam, const orc_options* o, int32_t x,
                   int32_t y, int32_t i, float* rgb3, orc_counters* c);

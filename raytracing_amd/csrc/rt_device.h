@@ -491,6 +491,17 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 // pending triangles are tested together, one per lane and turn, once enough lanes hold one (pend_min), a lane holds
 // pend_full of them, or no lane has an inner node left.  Persistent waves, per-shard fetch cursors and LDS/private
 // stack as in trace_queue.  sink(queue index, tag = the ray's dir.w bits, occluded) is called once per ray.
+//
+// ONE step outside the reference's procedure: a child box whose entry distance exceeds the segment's end by more than
+// a margin (dist >= tmax * 1.0001 + 1e-6) is not entered.  The reference enters it (its cull value `t` is infinite until a hit, Object.h:281,325-326) and then
+// rejects every triangle in it whose computed t exceeds tmax (Object.h:309).  A triangle lies inside its leaf box, so
+// its true distance is at least the box's entry distance; the answers can differ only if rounding makes a triangle's
+// COMPUTED t fall at or below tmax while the computed entry distance of a box around it lies beyond tmax plus the
+// margin (without the margin this happens at the ulp level, e.g. for tmax = the computed t of a triangle whose box is
+// flat; with it, only for a ray grazing a large triangle so closely that its t is meaningless).  No such ray has been seen: the
+// parity tests compare this walk with the oracle's reference-faithful walk, flag for flag (tests/test_gpu_trace.py,
+// test_golden.py, test_gpu_scale.py: 2.4 M segments, random and light-directed).  It removes 19 % of the inner visits
+// and 41 % of the triangle tests of the bench workload's shadow rays (they end 1e-3 in front of a tessellated light).
 template <class Sink>
 RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                             const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
@@ -499,7 +510,7 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
     V3 o(0.f), d(0.f);
     RaySlab rs;
     rs.oxy = rs.ozz = rs.ixy = rs.izz = f2{0.f, 0.f};
-    float tmax = 0.f;
+    float tmax = 0.f, tcull = 0.f;
     uint32_t q = 0, tag = 0;
     bool exact = false;
     bool wave_exact = false; // wave-uniform: some lane fetched a ray that needs the select-form slab test
@@ -520,6 +531,10 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 d = V3(d4);
                 rs = ray_slab(o4, d4, &exact);
                 tmax = o4.w;
+                // boxes entered beyond the segment's end (plus a margin of 1e-4 relative + 1e-6, a thousand times the
+                // rounding of the slab and triangle arithmetic on well-conditioned input) are skipped; a segment that
+                // cannot hold an accepted hit (tmax <= 0) skips everything, a non-finite tmax nothing
+                tcull = (tmax > 0.f && tmax < INFINITY) ? tmax * 1.0001f + 0.000001f : (tmax <= 0.f ? tmax : INFINITY);
                 sp = 0;
                 if (sc.root_ref >= 0) {
                     cur = sc.root_ref;
@@ -547,8 +562,8 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 bool lh, rh;
                 if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
                 else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
-                lh = lh && ld < INFINITY; // `dist < t` of Object.h:325-326 with t still infinite
-                rh = rh && rd < INFINITY;
+                lh = lh && ld < tcull; // `dist < t` of Object.h:325-326 with t still infinite, and dist <= tmax
+                rh = rh && rd < tcull;
                 if (lh && lref < 0) {
                     pend[np * RT_TRAV_BLOCK] = lref;
                     np++;

@@ -74,6 +74,8 @@ def lib():
         L.orc_rng_key.restype = u32
         L.orc_rng_draw.argtypes = [u32, u32]
         L.orc_rng_draw.restype = f32
+        L.orc_count_product_occlusion_walk.argtypes = [C.c_int32]
+        L.orc_count_product_occlusion_walk.restype = None
         L.orc_radiance.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcCamera), C.POINTER(OrcOptions), i32, i32, i32, vp, vp]
         L.orc_render.argtypes = [C.POINTER(OrcScene), C.POINTER(OrcCamera), C.POINTER(OrcOptions), vp, C.POINTER(OrcCounters)]
         L.orc_resolve.argtypes = [vp, i32, i32, i32, f32, vp]

@@ -126,3 +126,38 @@ def test_host_scene_api(rta, orc, room):
     assert sc.any_hit(ray)
     ray["d"] = (0, 0, 1)
     assert sc.closest_hit(ray) is None and not sc.any_hit(ray)
+
+
+def test_light_directed_segments_match_the_reference_walk(rta, orc, cornell):
+    """Shadow segments as next-event estimation makes them: from surface points towards points on the emissive mesh,
+    ending 1e-3 in front of it (main.cpp:278-281).  The kernels skip boxes entered beyond the segment's end; the oracle
+    walks like the reference (no such skip).  The flags must agree for every one of the ~1.7 million segments."""
+    sc, osc = cornell
+    tris, verts = sc.array(rta.ARR_TRIS), sc.array(rta.ARR_VERTS)
+    emitters = np.flatnonzero(tris["material"] == 5)  # Suzanne (material 5 of cornellbox.glb)
+    assert len(emitters) == 968
+    rng = np.random.default_rng(61)
+    n = 2_000_000
+    # surface points: first hits of random rays inside the room
+    prim = scenes.random_rays(n, 62, lo=(-1.6, 0.1, -1.6), hi=(1.6, 3.3, 1.6))
+    hits, _ = orc.closest_hit(osc, prim)
+    ok = hits["tri"] >= 0
+    prim, hits = prim[ok], hits[ok]
+    p = prim["o"] + prim["d"] * hits["t"][:, None]
+    # points on the light: uniform barycentrics on random emissive triangles
+    pick = emitters[rng.integers(0, len(emitters), len(p))]
+    pv = verts["pos"][tris["idx"][pick].astype(np.int64)]
+    b = rng.random((len(p), 2)).astype(np.float32)
+    su = np.sqrt(b[:, 0])
+    u, v = 1.0 - su, b[:, 1] * su
+    target = pv[:, 0] + u[:, None] * (pv[:, 1] - pv[:, 0]) + v[:, None] * (pv[:, 2] - pv[:, 0])
+    d = target - p
+    length = np.linalg.norm(d, axis=1).astype(np.float32)
+    seg = np.zeros(len(p), orc.RAY)
+    seg["o"] = (p - 1e-4 * prim["d"]).astype(np.float32)
+    seg["d"] = (d / length[:, None]).astype(np.float32)
+    tmax = (length - np.float32(0.001)).astype(np.float32)
+    got = sc.trace_any(seg, tmax)
+    want = orc.any_hit(osc, seg, tmax)
+    assert np.array_equal(got, want), np.count_nonzero(got != want)
+    assert 0.03 < want.mean() < 0.97  # both answers are well represented (1.7 M segments, ~10 % unoccluded)

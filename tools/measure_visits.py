@@ -32,7 +32,9 @@ else:  # BASELINE config 3: 1 000 000 random triangles, primary + shadow rays on
     label = "1 000 000 random triangles in the unit box (seed 1234), one rectangle light, depth 1"
     name = "visits_random1m_1080p_d1.json"
 osc = orc.scene_from_host(sc)
+orc.lib().orc_count_product_occlusion_walk(1)  # shadow-ray visits of the walk the kernels run (boxes beyond tmax skipped)
 _, c = orc.render(osc, cam, W, H, SPP, DEPTH, seed=1, spp_total=1024)
+orc.lib().orc_count_product_occlusion_walk(0)
 
 
 def entry(inner, leaf, rays):
