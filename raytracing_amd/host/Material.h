@@ -25,6 +25,26 @@ private:
     vec3 color;
 };
 
+// Material.h:25-41.  `grid` is stored as PI / grid and the cell test compares modulo(u, grid) with half of it, as the
+// reference does.  (Triangle-mesh hits carry no uv — Object.h:350-355 never writes si.u / si.v — so on the mesh path
+// a checkered albedo evaluates at u = v = 0: its `even` colour.)
+class CheckeredTexture : public Texture {
+public:
+    CheckeredTexture(vec3 even_, vec3 odd_, float grid_ = 0.25f) : even(even_), odd(odd_), grid(3.14159265358979323846f / grid_) {}
+    vec3 sample(float u, float v, vec3) const override {
+        auto modulo = [](float a, float b) { // Math.h:39-42
+            float r = std::fmod(a, b);
+            return (r < 0) ? r + b : r;
+        };
+        const bool odd_cell = (modulo(u, grid) < grid * 0.5) ^ (modulo(v, grid) < grid * 0.5);
+        return odd_cell ? odd : even;
+    }
+
+private:
+    vec3 even, odd;
+    float grid;
+};
+
 class Material { // Material.h:43-63
 public:
     virtual ~Material() {}
