@@ -3,8 +3,9 @@
 //
 //   k_generate    hammersley_2d + Camera::get_ray          (Scene.h:61-75)
 //   k_closest     TriangleMesh::intersect traversal        (Object.h:273-357)
-//   k_shade       get_ray_color body + shade_direct_NEE    (main.cpp:240-441)
-//                 + wave64 ballot/prefix-sum compaction of the next ray queue
+//   k_classify    lists the bounce's hits per material type (no reference counterpart: replaces virtual dispatch)
+//   k_shade_t<T>  get_ray_color body + shade_direct_NEE    (main.cpp:240-441), one launch per material type,
+//                 + wave64 ballot/prefix-sum compaction of the next ray queue and of the shadow queue
 //   k_shadow      trace_scene as a boolean                 (main.cpp:250,281)
 //   k_nee_resolve radiance += throughput * direct          (main.cpp:430)
 //   k_accumulate  NaN guard + per-pixel sum                (main.cpp:984-987)
