@@ -192,14 +192,12 @@ void Scene::add_rectangle_light(vec3 normal, float u_length, float v_length, vec
 void Scene::add_instance(const Mesh& mesh, const mat4& model_to_world, int material_override) {
     const Transform tf(model_to_world);
     const uint32_t base = (uint32_t)sceneMergedMesh.verts.size();
-    sceneMergedMesh.verts.reserve(sceneMergedMesh.verts.size() + mesh.verts.size());
     for (const Vertex& v : mesh.verts) {
         Vertex w = v;
         w.position = tf.to_world_point(v.position);
         w.normal = normalize(tf.to_world_normal(v.normal));
         sceneMergedMesh.verts.push_back(w);
     }
-    sceneMergedMesh.triangles.reserve(sceneMergedMesh.triangles.size() + mesh.triangles.size());
     for (MeshTriangle t : mesh.triangles) {
         for (int c = 0; c < 3; c++) t.indicies[c] += base;
         if (material_override >= 0) t.materialIndex = (uint32_t)material_override;

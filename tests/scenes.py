@@ -143,6 +143,29 @@ def cornell_with_instances(rta, n_lat, n_lon, copies, seed=99):
     return sc
 
 
+def sphere_field(rta, n_spheres=10_000, n_lat=16, n_lon=32, seed=1234):
+    """BASELINE config 4 geometry: n_spheres tessellated spheres (2 n_lon (n_lat - 1) triangles each: 960 -> 9.6 M for
+    10 000) on a jittered 22 x 22 x 21 grid in the unit box, one Lambert and one GGX material, a rectangle light on top."""
+    rng = np.random.default_rng(seed)
+    sc = rta.Scene()
+    sc.add_material(rta.material(rta.MAT_MATTE, (0.7, 0.7, 0.7)))
+    sc.add_material(rta.material(rta.MAT_GGX, s=(0.4, 0.0)))
+    v, t = uv_sphere(rta, n_lat, n_lon)
+    nx, ny, nz = 22, 22, 21
+    cells = rng.permutation(nx * ny * nz)[:n_spheres]
+    for k, c in enumerate(cells):
+        ix, iy, iz = c % nx, (c // nx) % ny, c // (nx * ny)
+        centre = (np.array([ix / nx, iy / ny, iz / nz]) + (0.25 + 0.5 * rng.random(3)) / np.array([nx, ny, nz]))
+        m = np.eye(4)
+        m[:3, :3] *= 0.2 / nx * (0.6 + 0.4 * rng.random())
+        m[:3, 3] = centre
+        sc.add_instance(v, t, m.T.reshape(-1).astype(np.float32), material=k & 1)
+    lm = np.eye(4, dtype=np.float32)
+    lm[:3, 3] = (0.5, 1.2, 0.5)
+    sc.add_rect_light((0, -1, 0), 0.5, 0.5, (20, 20, 20), lm.T.reshape(-1))
+    return sc
+
+
 def random_triangles_camera(rta, width, height):
     """Config 3 view: the unit box of random_triangles() seen from +z."""
     return rta.camera(rta.look_at((0.5, 0.5, 2.6), (0.5, 0.5, 0.5), (0, 1, 0)), 39.6, width, height)

@@ -128,3 +128,33 @@ def test_instanced_5m_properties(rta, gpu):
     perm = np.random.default_rng(53).permutation(len(rays))
     again = sc.trace_closest(rays[perm])
     assert np.array_equal(again.view(np.uint8), hits[perm].view(np.uint8))
+
+
+def test_sphere_field_10m_properties(rta, gpu):
+    """BASELINE config 4 geometry at full size: 10 000 spheres x 960 triangles = 9.6 M triangles (BVH_MIDDLE tree; 614 MB
+    of child-pair records, beyond any cache), through occlusion <=> closest hit, batch-order independence and the radius
+    of the hit points (every hit lies on some sphere: within its tessellation error of a sphere centre)."""
+    sc = scenes.sphere_field(rta)
+    n = len(sc.array(rta.ARR_TRIS))
+    assert n == 10_000 * 960 + 2
+    sc.build(max_per_leaf=1, strategy=0)
+    sc.upload(gpu)
+    rays = scenes.random_rays(300_000, 71, lo=(-0.1, -0.1, -0.1), hi=(1.1, 1.1, 1.1))
+    hits = sc.trace_closest(rays)
+    hit = hits["tri"] >= 0
+    assert 0.3 < hit.mean() < 0.9999 and (hits["tri"][hit] < n).all()
+    inf = np.full(len(rays), np.inf, np.float32)
+    assert np.array_equal(sc.trace_any(rays, inf).astype(bool), hit)
+    tm = np.where(hit, hits["t"], 1.0).astype(np.float32)
+    assert sc.trace_any(rays, tm).astype(bool)[hit].all() and not sc.trace_any(rays, (0.5 * tm).astype(np.float32)).astype(bool)[hit].any()
+    perm = np.random.default_rng(72).permutation(len(rays))
+    again = sc.trace_closest(rays[perm])
+    assert np.array_equal(again.view(np.uint8), hits[perm].view(np.uint8))
+    # the hit triangle contains the hit point: |p - (v0 + u e1 + v e2)| is rounding-small
+    verts, tris = sc.array(rta.ARR_VERTS), sc.array(rta.ARR_TRIS)
+    idx = np.flatnonzero(hit)[:50_000]
+    tv = verts["pos"][tris["idx"][hits["tri"][idx]].astype(np.int64)].astype(np.float64)
+    u, v = hits["u"][idx].astype(np.float64), hits["v"][idx].astype(np.float64)
+    on_tri = tv[:, 0] + u[:, None] * (tv[:, 1] - tv[:, 0]) + v[:, None] * (tv[:, 2] - tv[:, 0])
+    p = rays["o"][idx].astype(np.float64) + rays["d"][idx].astype(np.float64) * hits["t"][idx][:, None]
+    assert np.abs(p - on_tri).max() < 1e-4
