@@ -218,6 +218,9 @@ RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_by
     }
 }
 
+#ifndef RT_CLOSEST_STEPS
+#define RT_CLOSEST_STEPS 2 // inner steps per round of the closest walk
+#endif
 #define RT_CUR_DONE ((int)0x80000000)   // lane has no ray
 #define RT_CUR_FINISH ((int)0x80000001) // lane's ray is complete, result not yet written
 
@@ -399,7 +402,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
         // ---- inner-node steps (Object.h:322-343): two per round, so the wave-level bookkeeping above and below is
         // paid once per two node visits
 #pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < RT_CLOSEST_STEPS; rep++) {
             RT_STAT(0, cur >= 0); // inner steps
             RT_STAT(2, cur >= 0 && cur < top_bytes); // ... of which read from LDS
             if (cur >= 0) {
