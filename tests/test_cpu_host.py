@@ -55,6 +55,22 @@ def test_bvh_build_matches_oracle_bit_for_bit(rta, orc, n, leaf, strategy, degen
     assert leaves["count"].sum() == n and leaves["count"].max() <= leaf
 
 
+def test_threaded_sah_build_is_bit_identical(rta, orc, monkeypatch):
+    """Above 32 768 primitives the SAH build spreads candidate planes and small subtrees over threads; node numbering
+    is fixed in advance (2n - 1 nodes per n-primitive subtree), so nodes and indices equal the oracle's one-thread
+    recursion bit for bit — including coincident primitives (median fallback) inside the threaded part."""
+    n = 40_000
+    b = _random_bounds(n, 99, False)
+    b[1000:1400] = b[1000]  # 400 coincident boxes: no plane separates them
+    monkeypatch.setenv("RT_BVH_THREADS", "5")
+    hn, hi = rta.bvh_build(b, 1, 1)
+    on, oi = orc.bvh_build(b, 1, 1)
+    assert len(hn) == 2 * n - 1 and hn.tobytes() == on.tobytes() and np.array_equal(hi, oi)
+    monkeypatch.setenv("RT_BVH_THREADS", "1")
+    sn, si = rta.bvh_build(b, 1, 1)
+    assert sn.tobytes() == hn.tobytes() and np.array_equal(si, hi)
+
+
 def test_tri_bounds_and_mesh_build(rta, orc):
     sc = scenes.quad_room(rta)
     sc.build()
