@@ -239,7 +239,10 @@ int rt_trace_closest(rt_scene* scene, const rt_ray* rays, int64_t n, rt_hit* hit
 /* Replaces Scene::trace_scene(Ray, 0, tmax, &tmp) used as a boolean
  * occlusion test (Scene.h:113-129; call sites main.cpp:250,281) — what the
  * declared-but-undefined Scene::any_hit (Scene.h:133) was to be.
- * occluded[i] = 1 if any triangle is hit with 1e-4 < t <= tmax[i]. */
+ * occluded[i] = 1 if any triangle is hit with 1e-4 < t <= tmax[i].
+ * The walk skips boxes entered beyond tmax * 1.0001 + 1e-6 (the reference enters them and rejects their triangles one
+ * by one): same flags unless rounding puts a triangle's computed t at or below tmax while a box around it starts beyond
+ * that margin (never observed, compared flag for flag with the reference's procedure in tests/). */
 int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* tmax, int64_t n,
                  uint8_t* occluded);
 
