@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 16
+WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 16  # (main() raises the raster for --workload spheres10m)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 VISITS_JSON = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
 # rocprofv3 --pmc passes over `bench.py --steps 1` (tools/profile_pmc.sh + tools/summarize_pmc.py), FETCH_SIZE doubled as
@@ -58,6 +58,7 @@ def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
 
 
 def main():
+    global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
@@ -65,8 +66,9 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["cornellbox", "random1m"], default="cornellbox",
-                    help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow rays only")
+    ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m"], default="cornellbox",
+                    help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow "
+                         "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces")
     args = ap.parse_args()
 
     import numpy as np
@@ -106,13 +108,21 @@ def main():
         sc.build()
         cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
         label = "cornellbox.glb"
-    else:  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
+    elif args.workload == "random1m":  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
         sc = scenes.random_triangles(rta, 1_000_000)
-        sc.build()  # the reference's SAH builder: ~40 s
+        sc.build()  # the reference's SAH builder (multi-threaded, same output)
         cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
         depth = 1
         visits_json = os.path.join(ROOT, "profiles", "visits_random1m_1080p_d1.json")
         label = "1M random triangles (seed 1234), one rectangle light"
+    else:  # BASELINE configs[3] geometry, one GPU's share: 614 MB of pair records + 922 MB of triangles and normals, beyond every cache
+        WIDTH, HEIGHT = 3840, 2160
+        sc = scenes.sphere_field(rta)
+        sc.build()
+        cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
+        sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
+        visits_json = os.path.join(ROOT, "profiles", "visits_spheres10m_4k_d8.json")
+        label = "10 000 tessellated spheres (9.6M triangles, seed 1234), rectangle light + uniform environment"
     t_build = time.time() - t0
     sc.upload(local_rank)
 
@@ -221,8 +231,8 @@ def main():
             a_gbps = a_rays * v["bytes_per_ray"] / (a_ms * 1e-3) / 1e9
             out["roofline"]["standalone"] = {"achieved": a_gbps, "frac": a_gbps / HBM_PEAK_GBPS, "avg_launch_ms": a_ms / max(a_n, 1),
                                              "launches": a_n, "ms_per_step": alone["ms_total"],
-                                             "note": "untimed extra step, one pass at a time; the tree is L2/LDS-resident on cornellbox, so "
-                                                     "algorithmic bytes are not HBM bytes (see traffic)"}
+                                             "note": "untimed extra step, one pass at a time" + ("; the tree is L2/LDS-resident on cornellbox, so "
+                                                     "algorithmic bytes are not HBM bytes (see traffic)" if args.workload == "cornellbox" else "")}
         out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
         if not args.no_cpu_baseline and world == 1 and args.workload == "cornellbox":
             out["cpu_baseline"] = cpu_baseline(scenes, rta, sc)

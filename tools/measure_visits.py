@@ -24,6 +24,15 @@ if WORKLOAD == "cornellbox":
     cam = scenes.cornell_camera(rta, sc, W, H)
     label = f"cornellbox.glb GGX+Beckmann, depth {DEPTH}, camera of the file"
     name = "visits_cornellbox_1080p_d8.json"
+elif WORKLOAD == "spheres10m":  # BASELINE config 4 geometry: 9.6 M triangles (the SAH build takes about a minute on 8 cores)
+    W, H, SPP, DEPTH = 480, 270, 1, 8
+    import numpy as np
+    sc = scenes.sphere_field(rta)
+    sc.build()
+    sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
+    cam = scenes.random_triangles_camera(rta, W, H)
+    label = "10 000 tessellated spheres (9.6 M triangles, seed 1234), rectangle light + uniform environment, depth 8"
+    name = "visits_spheres10m_4k_d8.json"
 else:  # BASELINE config 3: 1 000 000 random triangles, primary + shadow rays only (depth 1); the SAH build takes ~40 s
     W, H, SPP, DEPTH = 480, 270, 2, 1
     sc = scenes.random_triangles(rta, 1_000_000)
