@@ -46,6 +46,18 @@ def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
         done += spp
         spp = min(spp * 2, 1024 - done) or 1
     rays = total["rays_closest"] + total["rays_shadow"]
+
+    # two short side legs (SURVEY §8 d): one thread, and the reference's threading model — every thread drawing from ONE
+    # locked generator, as glibc rand() makes the reference do (Utils.h:7-10) — on the same tile at a few samples
+    def leg(threads, shared, seconds):
+        n, t, r = 1, 0.0, 0
+        while t < seconds and n <= 64:
+            _, c = orc.render(osc, cam, WIDTH, HEIGHT, n, DEPTH, seed=2, spp_total=1024, tile=tile, threads=threads, shared_rng=shared)
+            t += c["seconds"]
+            r += c["rays_closest"] + c["rays_shadow"]
+            n *= 2
+        return r / t / 1e6
+
     return {
         "value": rays / total["seconds"] / 1e6,
         "unit": "Mrays/s",
@@ -54,6 +66,8 @@ def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
         "samples_per_s": total["paths"] / total["seconds"],
         "sample": f"oracle/ CPU restatement, {cores} threads, thread-local counter RNG, 480x270 central tile of the 1080p "
                   f"raster, {done} spp, depth {DEPTH}: {total['paths']} paths, {rays} rays in {total['seconds']:.1f} s",
+        "one_thread_mrays_per_s": leg(1, 0, 4.0),
+        "shared_locked_rng_mrays_per_s": leg(cores, 1, 4.0),
     }
 
 
