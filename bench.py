@@ -218,7 +218,7 @@ def main():
         # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
         visits = json.load(open(visits_json)) if os.path.exists(visits_json) else None
         kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"
-        if visits:
+        if visits and max(stats["ms_closest"], stats["ms_shadow"]) > 0:
             v = visits["closest" if kern == "k_closest" else "shadow"]
             n_rays = stats["rays_closest"] if kern == "k_closest" else stats["rays_shadow"]
             ms = stats["ms_closest"] if kern == "k_closest" else stats["ms_shadow"]
