@@ -52,17 +52,19 @@ struct Wave {
     float4* q_o[2];   // origin.xyz, path id (bits)
     float4* q_d[2];   // dir.xyz, unused
     float4* hit;      // slot (bits), t, u, v
-    float4* q_T;      // throughput before this bounce's scatter (for NEE resolve)
     // path state, indexed by path id: ONE 64-byte record per path (a queue entry's path id is random, so every access
     // is its own HBM sector: three 16-byte arrays cost three sectors per read and three partial-line writes)
     //   [0] throughput.xyz, scatter_pdf   [1] radiance.xyz, rng key (bits)   [2] prev.point.xyz, rng counter (bits)   [3] spare
     float4* path;
-    // NEE: K slots per queue position, slot k of queue entry q at [k*cap + q]
-    float4* contrib;  // direct contribution of slot k (before throughput)
-    uint8_t* vis;     // 1 = shadow ray unoccluded
-    // dense shadow-ray queue
+    // Dense shadow-ray queue; the next-event-estimation records live in it, at the rays' own positions: a lane's shadow
+    // rays are consecutive entries and lanes reserve in order, so every NEE store is a coalesced 1-KiB burst.  (Records
+    // indexed by the shaded queue entry were scattered 16-byte writes in material order: with their resolve pass a third
+    // of all shading time.)
     float4* s_o;      // origin.xyz, tmax
-    float4* s_d;      // dir.xyz, target index k*cap + q (bits)
+    float4* s_d;      // dir.xyz, -
+    float4* s_c;      // direct contribution of this ray (before throughput), path id + 1 (bits) on a path's FIRST ray else 0
+    float4* s_T;      // first ray only: throughput before this bounce's scatter, number of rays of the path (bits)
+    uint8_t* vis;     // 1 = shadow ray unoccluded, written by k_shadow at the ray's position
     // counters: [b*S + s] live rays of shard s entering bounce b (bounce 0: shard s = the s-th shard_cap entries of the
     // dense camera-ray queue), [64*S + b*S + s] shadow rays of shard s made at bounce b
     // Counter i lives at word i * RT_CSTRIDE (one 128-byte line each).
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const fl
     __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
     const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
     occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
-                    top_bytes, [&](uint32_t, uint32_t target, bool occluded) { vis[target] = occluded ? 0 : 1; });
+                    top_bytes, [&](uint32_t q, uint32_t, bool occluded) { vis[q] = occluded ? 0 : 1; });
 }
 
 // Parity hook variant: rays + tmax in, occluded flag out (rt_trace_any).
@@ -290,7 +292,6 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
     V3 T(tp);
     const float scatter_pdf = tp.w;
     V3 rad(rk);
-    float4 nee_T = make_float4(0.f, 0.f, 0.f, 0.f); // .w = path id + 1 (bits) when this entry has NEE slots to resolve, else 0
     SH_MARK(0); // queue + path state loads
 
     if (KEY == RT_KEY_MISS) { // main.cpp:340-359
@@ -302,7 +303,6 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             rad = rad + (T * bg) * mw;
             ps[1] = pack(rad, rk.w);
         }
-        w.q_T[q] = nee_T;
         SH_MARK(1); // miss: environment lookup
         return;
     }
@@ -345,10 +345,7 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
 
     Scatter scat = mat_sample(mat, si, rd, rng);
     SH_MARK(3); // Sample_Eval
-    if (fabsf(scat.pdf) < 0.000001f) { // main.cpp:410-412: the path ends BEFORE next-event estimation
-        w.q_T[q] = nee_T;
-        return;
-    }
+    if (fabsf(scat.pdf) < 0.000001f) return; // main.cpp:410-412: the path ends BEFORE next-event estimation
 
     // shade_direct_NEE, main.cpp:240-317: contributions are computed here, the visibility
     // tests run in k_shadow over a dense queue, k_nee_resolve applies them in slot order.
@@ -365,22 +362,23 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             float mis = power_heuristic(env_pdf, bp);
             env_c = ((mis * f) * col) / env_pdf;
         }
-        w.contrib[q] = pack(env_c, 0.f); // without a shadow ray the slot's vis byte is stale, and its contribution an exact zero
     }
     SH_MARK(4); // environment NEE
-    // one reservation for all of this wave's shadow rays: [env ray] + one per light, contiguous per lane
+    // one reservation for all of this wave's shadow rays: [env ray] + one per light, contiguous per lane.  A slot
+    // without a ray (the environment direction below the surface) contributes an exact zero and is simply left out.
+    const uint32_t n_rays = (uint32_t)sc.n_lights + (want_env ? 1u : 0u);
     uint32_t j = out_shard * (uint32_t)pp.K * pp.shard_cap +
                  wave_reserve((uint32_t)sc.n_lights, want_env, &w.counts[(size_t)(64u * pp.n_shards + (uint32_t)bounce * pp.n_shards + out_shard) * RT_CSTRIDE]);
-    int k = 0;
-    if (pp.has_env) {
-        if (want_env) {
-            w.s_o[j] = pack(sh_origin, INFINITY);
-            w.s_d[j] = pack(env_dir, __uint_as_float(q));
-            j++;
-        }
-        k = 1;
+    if (n_rays) w.s_T[j] = pack(T, __uint_as_float(n_rays)); // T before the scatter (main.cpp:430 uses it before 434 updates it)
+    uint32_t first_tag = (uint32_t)p + 1u;
+    if (want_env) {
+        w.s_o[j] = pack(sh_origin, INFINITY);
+        w.s_d[j] = pack(env_dir, 0.f);
+        w.s_c[j] = pack(env_c, __uint_as_float(first_tag));
+        first_tag = 0u;
+        j++;
     }
-    for (int i = 0; i < sc.n_lights; i++, k++, j++) {
+    for (int i = 0; i < sc.n_lights; i++, j++) {
         const rt_light& L = sc.lights[__builtin_amdgcn_readfirstlane(i)]; // wave-uniform: read through the scalar cache
         V3 point, normal;
         light_sample(sc, tb, L, rng, &point, &normal);
@@ -398,14 +396,12 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             c = (((mis * f) / lpdf) * 1.f) * mat_emitted(sc.materials[L.material]);
         }
         // the reference traces this ray before it looks at denom (main.cpp:281-295)
-        const uint32_t target = (uint32_t)k * pp.capq + q;
         w.s_o[j] = pack(sh_origin, length - 0.001f);
-        w.s_d[j] = pack(ld, __uint_as_float(target));
-        w.contrib[target] = pack(c, 0.f); // k_shadow writes vis[target] for every queued ray
+        w.s_d[j] = pack(ld, 0.f);
+        w.s_c[j] = pack(c, __uint_as_float(first_tag));
+        first_tag = 0u;
     }
     SH_MARK(5); // light NEE
-    nee_T = pack(T, __int_as_float(p + 1));
-    w.q_T[q] = nee_T;
 
     T = (T * scat.f) / scat.pdf; // main.cpp:434
     ps[0] = pack(T, scat.pdf);
@@ -479,17 +475,24 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView 
     }
 }
 
-// radiance += throughput * direct (main.cpp:430), slots summed in reference order
+// radiance += throughput * direct (main.cpp:430), a path's slots summed in reference order (environment ray, then the
+// lights).  One lane per shadow-queue entry; the lane of a path's FIRST ray does the path's sum (its rays are consecutive).
 __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp, int bounce) {
-    const uint32_t q = blockIdx.x * RT_BLOCK + threadIdx.x;
-    bool block_idle;
-    if (!queue_entry_live(w, pp, bounce, q, &block_idle)) return;
-    const float4 T4 = w.q_T[q];
-    const int p = __float_as_int(T4.w) - 1; // (the ray queue entry need not be read for the path id)
-    if (p < 0) return;
+    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t shard_span = (uint32_t)pp.K * pp.shard_cap; // shadow-queue entries reserved per shard
+    const uint32_t shard = j / shard_span;
+    if (shard >= pp.n_shards) return;
+    const uint32_t live = w.counts[(size_t)(64u * pp.n_shards + (uint32_t)bounce * pp.n_shards + shard) * RT_CSTRIDE];
+    if (j - shard * shard_span >= live) return;
+    const float4 c0 = w.s_c[j];
+    const int p = (int)__float_as_uint(c0.w) - 1;
+    if (p < 0) return; // not a path's first ray
+    const float4 T4 = w.s_T[j];
+    const uint32_t n = __float_as_uint(T4.w);
     V3 direct(0.f);
-    for (int k = 0; k < pp.K; k++)
-        if (w.vis[(size_t)k * pp.capq + q]) direct = direct + V3(w.contrib[(size_t)k * pp.capq + q]);
+    if (w.vis[j]) direct = direct + V3(c0);
+    for (uint32_t r = 1; r < n; r++)
+        if (w.vis[j + r]) direct = direct + V3(w.s_c[j + r]);
     float4* pr = w.path + 4 * (size_t)p + 1;
     const float4 rk = *pr;
     V3 rad(rk);
@@ -599,9 +602,9 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
         if ((rc = wave_alloc(s, &w.q_d[i], c))) return rc;
     }
     if ((rc = wave_alloc(s, &w.hit, c))) return rc;
-    if ((rc = wave_alloc(s, &w.q_T, c))) return rc;
     if ((rc = wave_alloc(s, &w.path, 4 * c))) return rc;
-    if ((rc = wave_alloc(s, &w.contrib, kc))) return rc;
+    if ((rc = wave_alloc(s, &w.s_c, kc))) return rc;
+    if ((rc = wave_alloc(s, &w.s_T, kc))) return rc;
     if ((rc = wave_alloc(s, &w.vis, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_o, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_d, kc))) return rc;
@@ -1033,7 +1036,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
                                    shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);
             mark();
             mark();
-            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(b == 0 ? grid0 : gridq), dim3(RT_BLOCK), 0, st, wave, pp, b);
+            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(blocks_for((int64_t)K * pp.capq)), dim3(RT_BLOCK), 0, st, wave, pp, b);
             mark();
         }
         mark();
