@@ -170,6 +170,37 @@ typedef struct rt_scene_desc {
     float env_offset;
 } rt_scene_desc;
 
+/* ---- legacy two-level scenes: Scene::instances under a TLAS (Scene.cpp:6-77), Instance (Object.h:364-423) over the
+ * Geometry classes (Object.h:26-243 analytic, 266-362 TriangleMesh).  SURVEY 8 f-2. */
+enum {
+    RT_GEO_MESH = 0,      /* TriangleMesh  Object.h:266-362  blas_root = its BVH within rt_scene_desc.pairs / tris (model space) */
+    RT_GEO_SPHERE = 1,    /* Sphere        Object.h:26-60    p0 = radius                                            */
+    RT_GEO_RECTANGLE = 2, /* Rectangle     Object.h:61-135   p0-2 N, p3-5 T, p6-8 B, p9 u, p10 v (half side lengths) */
+    RT_GEO_DISK = 3,      /* Disk          Object.h:137-168  p0-2 normal, p3 outer_radius, p4 inner_radius          */
+    RT_GEO_BOX = 4,       /* Box           Object.h:170-209  p0-2 bmin, p3-5 bmax                                   */
+    RT_GEO_CYLINDER = 5   /* Cylinder      Object.h:211-243  p0 radius, p1 ymin, p2 ymax                            */
+};
+typedef struct rt_instance {
+    int32_t geometry;
+    int32_t material;  /* Instance::material: replaces the triangles' own (Object.h:387) */
+    int32_t blas_root; /* RT_GEO_MESH: child-ref encoding of the mesh BVH's node 0 (refs index rt_scene_desc.pairs / tris) */
+    int32_t reserved;
+    float area;        /* Instance::get_area (Object.h:404-407): Rectangle (2u)(2v), every other Geometry 0 */
+    float p[11];
+    float m[16];       /* Transform: model-to-world, column-major (Math.h:641-698) */
+    float inv_m[16];   /* world-to-model */
+} rt_instance;
+
+/* The TLAS (BVH::build(world bounds, 1, BVH_SAH), Scene.cpp:6-15) as child-pair records; a leaf ref is ~instance index
+ * (one instance per leaf). */
+typedef struct rt_tlas_desc {
+    int32_t root_ref;
+    int64_t n_pairs;
+    const rt_bvh_pair* pairs;
+    int32_t n_instances;
+    const rt_instance* instances;
+} rt_tlas_desc;
+
 enum { RT_FILTER_GAUSSIAN = 0, RT_FILTER_BOX = 1 };
 
 /* Camera (Scene.h:10-81): raster_to_world and camera_pos as built by the
@@ -231,10 +262,24 @@ int rt_device_count(void);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* The legacy two-level scene: replaces Scene::build_top_level_bvh (Scene.cpp:6-15) + every TriangleMesh's own BVH
+ * (Object.cpp:11-29).  `geometry` holds the model-space BVHs and triangles of all meshes, concatenated (root_ref unused;
+ * n_tris may be 0; the triangles' material / light fields and emissive_tris are ignored; lights must be RT_LIGHT_RECT),
+ * plus materials, lights and environment as in rt_scene_create.  Every entry point below works on such a scene:
+ * closest hit walks the TLAS and, inside a mesh instance, the mesh's BVH with the ray in model space (Object.h:380-394);
+ * shadow queries answer Scene::trace_scene as a boolean (Scene.h:113-129), walking the TLAS instead of the reference's
+ * loop over all instances (an instance whose world bounds the segment misses is skipped). */
+int rt_scene_create_instanced(const rt_scene_desc* geometry, const rt_tlas_desc* tlas, int device, rt_scene** out);
+
 /* Replaces bool Scene::closest_hit(Ray, Intersection*) const
  * (Scene.cpp:17-77 over TriangleMesh::intersect, Object.h:273-357) for a
  * batch of n rays; host pointers. */
 int rt_trace_closest(rt_scene* scene, const rt_ray* rays, int64_t n, rt_hit* hits);
+
+/* The same with Intersection::index (Scene.cpp:42): index[i] = instance hit, -1 on a miss (0 on a hit in a scene without
+ * instances).  In a two-level scene hits[i].tri is the triangle's index within the instance's mesh, 0 for an analytic
+ * primitive; (u, v) are the Rectangle's si->u / si->v (Object.h:116-117) and 0 for the other analytic primitives. */
+int rt_trace_closest_indexed(rt_scene* scene, const rt_ray* rays, int64_t n, rt_hit* hits, int32_t* index);
 
 /* Replaces Scene::trace_scene(Ray, 0, tmax, &tmp) used as a boolean
  * occlusion test (Scene.h:113-129; call sites main.cpp:250,281) — what the

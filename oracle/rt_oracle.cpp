@@ -233,7 +233,7 @@ struct MeshHit {
 // cull_tmax is NOT the reference: it restates the one place where the product's occlusion walk leaves the reference's
 // procedure (boxes entered beyond the segment's end are skipped) and exists only so that
 // tools/measure_visits.py can count the nodes THAT walk visits.  Every parity check runs with cull_tmax = false.
-inline bool mesh_traverse(const orc_scene* s, const V3& o, const V3& d, float tmin, float tmax, bool any, MeshHit& out,
+inline bool mesh_traverse(const orc_mesh* s, const V3& o, const V3& d, float tmin, float tmax, bool any, MeshHit& out,
                           orc_visits* vis, bool cull_tmax = false) {
     int stack[64];
     stack[0] = 0;
@@ -295,6 +295,255 @@ inline bool mesh_traverse(const orc_scene* s, const V3& o, const V3& d, float tm
     }
     if (vis) { vis->inner = inner; vis->leaf = leaf; }
     return std::isfinite(t);
+}
+inline orc_mesh flat_mesh(const orc_scene* s) { // the merged mesh of a flat scene as a mesh view
+    orc_mesh m;
+    m.n_verts = s->n_verts;
+    m.verts = s->verts;
+    m.n_tris = s->n_tris;
+    m.tris = s->tris;
+    m.n_nodes = s->n_nodes;
+    m.nodes = s->nodes;
+    m.indices = s->indices;
+    return m;
+}
+inline bool mesh_traverse(const orc_scene* s, const V3& o, const V3& d, float tmin, float tmax, bool any, MeshHit& out,
+                          orc_visits* vis, bool cull_tmax = false) {
+    const orc_mesh m = flat_mesh(s);
+    return mesh_traverse(&m, o, d, tmin, tmax, any, out, vis, cull_tmax);
+}
+
+// ------------------------------------------------- legacy two-level scenes
+// Intersection as the Geometry classes fill it (Def.h:11-40); u, v, tri: what the C-ABI reports besides
+struct GeoHit {
+    float t = INFINITY;
+    V3 point = V3(0, 0, 0), normal = V3(0, 0, 0);
+    bool front_face = true;
+    float u = 0, v = 0;
+    int tri = 0;
+    void set_face_normal(const V3& dir, const V3& outward) { // Def.h:31-34
+        front_face = dot(dir, outward) < 0;
+        normal = front_face ? outward : -outward;
+    }
+    void set_forward_face(const V3& dir, const V3& outward) { // Def.h:35-39
+        bool front = dot(dir, outward) < 0;
+        front_face = true;
+        normal = front ? outward : -outward;
+    }
+};
+inline float c_fmin(float a, float b) { return (float)std::fmin((double)a, (double)b); } // ::fmin on floats, as written
+inline float c_fmax(float a, float b) { return (float)std::fmax((double)a, (double)b); }
+
+inline bool sphere_intersect(const float* p, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si) { // Object.h:34-55
+    const float radius = p[0];
+    V3 center(0, 0, 0);
+    V3 oc = o - center;
+    float a = dot(d, d);
+    float halfb = dot(oc, d);
+    float c = dot(oc, oc) - radius * radius;
+    float discriminant = halfb * halfb - a * c;
+    if (discriminant < 0) return false;
+    float sqrt_dist = std::sqrt(discriminant);
+    float root = (-halfb - sqrt_dist) / a;
+    if (root < tmin || root > tmax) {
+        root = (-halfb + sqrt_dist) / a;
+        if (root < tmin || root > tmax) return false;
+    }
+    si->t = root;
+    si->point = o + d * root; // Ray::at, Math.h:627-629
+    si->set_face_normal(d, (si->point - center) / radius);
+    return true;
+}
+inline bool rectangle_intersect(const float* p, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si) { // Object.h:93-120
+    const V3 N(p), T(p + 3), B(p + 6);
+    const float u = p[9], v = p[10];
+    float denom = dot(N, d);
+    if (std::fabs((double)denom) < 0.01) return false;
+    float dist = dot(o, N);
+    float t = -dist / denom;
+    if (t < tmin || t > tmax) return false;
+    V3 pi = o + d * t;
+    float u_dist = dot(pi, T);
+    if (u_dist < -u || u_dist > u) return false;
+    float v_dist = dot(pi, B);
+    if (v_dist < -v || v_dist > v) return false;
+    si->point = pi;
+    si->set_face_normal(d, N);
+    si->u = u_dist / u;
+    si->v = v_dist / v;
+    si->t = t;
+    return true;
+}
+inline bool disk_intersect(const float* p, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si) { // Object.h:141-162
+    const V3 normal(p);
+    const float outer_radius = p[3], inner_radius = p[4];
+    float denom = dot(normal, d);
+    if (std::fabs((double)denom) < 0.01) return false;
+    float dist = dot(o, normal);
+    float t = -dist / denom;
+    if (t < tmin || t > tmax) return false;
+    V3 pi = o + d * t;
+    float dist_radius = len(pi);
+    if (dist_radius > outer_radius || dist_radius < inner_radius) return false;
+    si->point = pi;
+    si->set_face_normal(d, normal);
+    si->t = t;
+    return true;
+}
+inline bool box_intersect(const float* p, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si) { // Object.h:175-204
+    float greatest_minimum = -INFINITY;
+    int gm_idx = 0; // (uninitialised in the reference; always assigned before use when the test passes with tmin >= 0)
+    for (int a = 0; a < 3; a++) {
+        float t0 = c_fmin((p[a] - o[a]) / d[a], (p[3 + a] - o[a]) / d[a]);
+        float t1 = c_fmax((p[a] - o[a]) / d[a], (p[3 + a] - o[a]) / d[a]);
+        tmin = c_fmax(t0, tmin);
+        tmax = c_fmin(t1, tmax);
+        if (tmax <= tmin) return false;
+        if (tmin > greatest_minimum) {
+            greatest_minimum = tmin;
+            gm_idx = a;
+        }
+    }
+    int idx = gm_idx;
+    float t = greatest_minimum;
+    float nrm[3] = {0, 0, 0};
+    nrm[idx] = (d[idx] > 0) ? -1.f : 1.f;
+    si->point = o + d * t;
+    si->set_face_normal(d, V3(nrm));
+    si->t = t;
+    return true;
+}
+inline bool cylinder_intersect(const float* p, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si) { // Object.h:216-239
+    const float radius = p[0], ymin = p[1], ymax = p[2];
+    float a = d.x * d.x + d.z * d.z;
+    float b = 2 * (o.x * d.x + o.z * d.z);
+    float c = o.x * o.x + o.z * o.z - radius * radius;
+    float discriminant = b * b - 4 * a * c;
+    if (discriminant < 0) return false;
+    float sqrt_dist = std::sqrt(discriminant);
+    float root = (-b - sqrt_dist) / (2 * a);
+    V3 point = o + d * root;
+    if (root < tmin || root > tmax || point.y < ymin || point.y > ymax) {
+        root = (-b + sqrt_dist) / (2 * a);
+        point = o + d * root;
+        if (root < tmin || root > tmax || point.y < ymin || point.y > ymax) return false;
+    }
+    V3 normal = V3(point.x, 0, point.z) / radius;
+    si->point = point;
+    si->set_forward_face(d, normal);
+    si->t = root;
+    return true;
+}
+// TriangleMesh::intersect (Object.h:273-357): the walk, then the interpolated normal
+inline bool trimesh_intersect(const orc_mesh* m, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si, orc_visits* vis) {
+    MeshHit h;
+    if (!mesh_traverse(m, o, d, tmin, tmax, false, h, vis)) return false;
+    const orc_triangle& tri = m->tris[h.tri];
+    si->point = o + d * h.t;
+    float bw = 1 - h.u - h.v; // bary = (bary_temp.z, .x, .y): weights of corners 0, 1, 2 (Object.h:317,351-353)
+    V3 N = bw * V3(m->verts[tri.idx[0]].normal) + h.u * V3(m->verts[tri.idx[1]].normal) + h.v * V3(m->verts[tri.idx[2]].normal);
+    si->set_face_normal(d, normalize(N));
+    si->t = h.t;
+    si->u = h.u;
+    si->v = h.v;
+    si->tri = h.tri;
+    return true;
+}
+inline V3 to_model_vector(const float* im, const V3& v) { // Math.h:675-683
+    return V3(im[0] * v.x + im[4] * v.y + im[8] * v.z, im[1] * v.x + im[5] * v.y + im[9] * v.z, im[2] * v.x + im[6] * v.y + im[10] * v.z);
+}
+inline V3 to_world_normal(const float* im, const V3& n) { // Math.h:667-674
+    return V3(im[0] * n.x + im[1] * n.y + im[2] * n.z, im[4] * n.x + im[5] * n.y + im[6] * n.z, im[8] * n.x + im[9] * n.y + im[10] * n.z);
+}
+// Instance::intersect, Object.h:380-394
+inline bool instance_intersect(const orc_two_level* tl, const orc_instance& I, const V3& o, const V3& d, float tmin, float tmax,
+                               GeoHit* si, orc_visits* vis) {
+    const V3 mo = m4_point(I.inv_m, o), md = to_model_vector(I.inv_m, d); // Transform::to_model_ray, Math.h:692-694
+    bool hit = false;
+    if (vis) vis->inner = vis->leaf = 0;
+    switch (I.geometry) {
+    case 0: hit = trimesh_intersect(&tl->meshes[I.mesh], mo, md, tmin, tmax, si, vis); break;
+    case 1: hit = sphere_intersect(I.p, mo, md, tmin, tmax, si); break;
+    case 2: hit = rectangle_intersect(I.p, mo, md, tmin, tmax, si); break;
+    case 3: hit = disk_intersect(I.p, mo, md, tmin, tmax, si); break;
+    case 4: hit = box_intersect(I.p, mo, md, tmin, tmax, si); break;
+    case 5: hit = cylinder_intersect(I.p, mo, md, tmin, tmax, si); break;
+    }
+    if (!hit) return false;
+    si->point = m4_point(I.m, si->point);
+    si->normal = normalize(to_world_normal(I.inv_m, si->normal));
+    return true;
+}
+// Scene::closest_hit, Scene.cpp:17-77.  *index = Intersection::index.  `res` keeps what earlier hits wrote, as the
+// reference's reused Intersection does; u, v and tri are reset per accepted hit (they are this build's report fields).
+inline bool scene_closest_hit(const orc_two_level* tl, const V3& o, const V3& d, GeoHit* res, int* index, orc_visits* vis) {
+    int stack[64];
+    stack[0] = 0;
+    int sp = 1;
+    float t = INFINITY;
+    int inner = 0, leaf = 0;
+    if (tl->n_instances <= 0) return false;
+    while (sp > 0) {
+        const orc_node* nd = &tl->tlas_nodes[stack[--sp]];
+        if (nd->count != -1) {
+            for (int i = 0; i < nd->count; i++) {
+                const int k = tl->tlas_indices[nd->left_node + i];
+                GeoHit tmp = *res;
+                tmp.u = tmp.v = 0;
+                tmp.tri = 0;
+                orc_visits iv;
+                bool hit = instance_intersect(tl, tl->instances[k], o, d, 0, t, &tmp, &iv);
+                inner += iv.inner;
+                leaf += iv.leaf;
+                if (!hit) continue;
+                *res = tmp;
+                t = res->t;
+                *index = k;
+            }
+            continue;
+        }
+        inner++;
+        float ld, rd;
+        const orc_node* L = &tl->tlas_nodes[nd->left_node];
+        const orc_node* R = &tl->tlas_nodes[nd->left_node + 1];
+        bool lh = slab(L->bmin, L->bmax, o, d, ld);
+        bool rh = slab(R->bmin, R->bmax, o, d, rd);
+        lh = lh && ld < t;
+        rh = rh && rd < t;
+        if (lh && rh) {
+            if (ld < rd) {
+                stack[sp++] = nd->left_node + 1;
+                stack[sp++] = nd->left_node;
+            } else {
+                stack[sp++] = nd->left_node;
+                stack[sp++] = nd->left_node + 1;
+            }
+        } else if (lh) {
+            stack[sp++] = nd->left_node;
+        } else if (rh) {
+            stack[sp++] = nd->left_node + 1;
+        }
+    }
+    if (vis) { vis->inner = inner; vis->leaf = leaf; }
+    return std::isfinite(t);
+}
+// Scene::trace_scene (Scene.h:113-129) as a boolean: the linear loop
+inline bool scene_trace_any(const orc_two_level* tl, const V3& o, const V3& d, float tmin, float tmax, orc_visits* vis) {
+    bool hit = false;
+    float closest_so_far = tmax;
+    int inner = 0, leaf = 0;
+    for (int i = 0; i < tl->n_instances; i++) {
+        GeoHit tmp;
+        orc_visits iv;
+        if (instance_intersect(tl, tl->instances[i], o, d, tmin, closest_so_far, &tmp, &iv)) {
+            hit = true;
+            closest_so_far = tmp.t;
+        }
+        inner += iv.inner;
+        leaf += iv.leaf;
+    }
+    if (vis) { vis->inner = inner; vis->leaf = leaf; }
+    return hit;
 }
 
 // ------------------------------------------------------------------- random
@@ -1004,7 +1253,8 @@ bool occluded(Ctx& c, const V3& o, const V3& d, float tmin, float tmax) {
     c.rays_shadow++;
     MeshHit h;
     orc_visits vis;
-    bool hit = mesh_traverse(c.s, o, d, tmin, tmax, true, h, &vis, g_count_product_occlusion_walk);
+    bool hit = c.s->two_level ? scene_trace_any(c.s->two_level, o, d, tmin, tmax, &vis)
+                              : mesh_traverse(c.s, o, d, tmin, tmax, true, h, &vis, g_count_product_occlusion_walk);
     c.s_inner += vis.inner;
     c.s_leaf += vis.leaf;
     return hit;
@@ -1136,9 +1386,12 @@ V3 radiance(Ctx& c, const orc_camera* cam, const orc_options* opt, int x, int y,
     V3 rad(0, 0, 0), T(1.f);
     for (int b = 0; b < opt->max_depth; b++) {
         MeshHit h;
+        GeoHit gh;
+        int hit_index = -1;
         orc_visits vis;
         c.rays_closest++;
-        bool hit = mesh_traverse(s, ro, rd, 0, INFINITY, false, h, &vis); // Scene.cpp:37: (r, 0, t = INF)
+        bool hit = s->two_level ? scene_closest_hit(s->two_level, ro, rd, &gh, &hit_index, &vis)
+                                : mesh_traverse(s, ro, rd, 0, INFINITY, false, h, &vis); // Scene.cpp:37: (r, 0, t = INF)
         c.inner += vis.inner;
         c.leaf += vis.leaf;
         if (!hit) { // main.cpp:340-359
@@ -1151,23 +1404,35 @@ V3 radiance(Ctx& c, const orc_camera* cam, const orc_options* opt, int x, int y,
             }
             break;
         }
-        // TriangleMesh::intersect tail, Object.h:350-355
-        const orc_triangle& tri = s->tris[h.tri];
-        si.point = ro + rd * h.t;
-        float bw = 1 - h.u - h.v;
-        V3 N = bw * V3(s->verts[tri.idx[0]].normal) + h.u * V3(s->verts[tri.idx[1]].normal) + h.v * V3(s->verts[tri.idx[2]].normal);
-        N = normalize(N);
-        si.front_face = dot(rd, N) < 0; // Def.h:31-34
-        si.normal = si.front_face ? N : -N;
-        const orc_material* mat = &s->materials[tri.material];
-        int light = s->tri_light ? s->tri_light[h.tri] : -1;
+        const orc_material* mat;
+        float hit_area; // world.instances[si.index].get_area(), main.cpp:376
+        if (s->two_level) {
+            const orc_instance& I = s->two_level->instances[hit_index];
+            si.point = gh.point;
+            si.normal = gh.normal;
+            si.front_face = gh.front_face;
+            mat = &s->materials[I.material]; // Object.h:387
+            hit_area = I.area;
+        } else {
+            // TriangleMesh::intersect tail, Object.h:350-355
+            const orc_triangle& tri = s->tris[h.tri];
+            si.point = ro + rd * h.t;
+            float bw = 1 - h.u - h.v;
+            V3 N = bw * V3(s->verts[tri.idx[0]].normal) + h.u * V3(s->verts[tri.idx[1]].normal) + h.v * V3(s->verts[tri.idx[2]].normal);
+            N = normalize(N);
+            si.front_face = dot(rd, N) < 0; // Def.h:31-34
+            si.normal = si.front_face ? N : -N;
+            mat = &s->materials[tri.material];
+            int light = s->tri_light ? s->tri_light[h.tri] : -1;
+            hit_area = light >= 0 ? s->lights[light].area : 0.f; // Geometry::area() default, Object.h:18-20
+        }
 
         V3 emitted = mat_emitted(mat);
         float weight = 1.f;
         if (b > 0 && dot(emitted, V3(1.0f)) > 0.1) { // main.cpp:373-396
             float brdf_pdf = scatter_pdf;
             float cos_light = fmax_sel(dot(rd, -si.normal), 0);
-            float area = light >= 0 ? s->lights[light].area : 0.f; // Geometry::area() default, Object.h:18-20
+            float area = hit_area;
             float denom = area * cos_light;
             if (denom <= 0 || !si.front_face) {
                 weight = 0;
@@ -1241,6 +1506,76 @@ void orc_any_hit(const orc_scene* s, const orc_ray* rays, const float* tmax, int
         MeshHit h;
         occ[i] = mesh_traverse(s, V3(rays[i].o), V3(rays[i].d), 0, tmax[i], true, h, nullptr) ? 1 : 0;
     }
+}
+
+void orc_closest_hit2(const orc_scene* s, const orc_ray* rays, int64_t n, orc_hit* hits, int32_t* index, float* normal3, uint8_t* front) {
+    for (int64_t i = 0; i < n; i++) {
+        GeoHit g;
+        int k = -1;
+        bool hit = scene_closest_hit(s->two_level, V3(rays[i].o), V3(rays[i].d), &g, &k, nullptr);
+        hits[i].tri = hit ? g.tri : -1;
+        hits[i].t = hit ? g.t : INFINITY;
+        hits[i].u = hit ? g.u : 0;
+        hits[i].v = hit ? g.v : 0;
+        if (index) index[i] = hit ? k : -1;
+        if (normal3) (hit ? g.normal : V3(0, 0, 0)).store(normal3 + 3 * i);
+        if (front) front[i] = hit && g.front_face ? 1 : 0;
+    }
+}
+
+void orc_any_hit2(const orc_scene* s, const orc_ray* rays, const float* tmax, int64_t n, uint8_t* occ) {
+    for (int64_t i = 0; i < n; i++) occ[i] = scene_trace_any(s->two_level, V3(rays[i].o), V3(rays[i].d), 0, tmax[i], nullptr) ? 1 : 0;
+}
+
+void orc_world_bounds(const float* obj6, const float* m, float* out6) { // Math.h:800-812
+    const V3 lo(obj6), hi(obj6 + 3);
+    Box b;
+    b.lo = b.hi = m4_point(m, lo); // Bounds(vec3), Math.h:746
+    auto add = [&](const V3& p) { // bounds_union(Bounds, vec3), Math.h:794-799
+        V3 w = m4_point(m, p);
+        b.lo = vmin(b.lo, w);
+        b.hi = vmax(b.hi, w);
+    };
+    add(V3(hi.x, lo.y, lo.z));
+    add(V3(hi.x, lo.y, hi.z));
+    add(V3(lo.x, lo.y, hi.z));
+    add(V3(lo.x, hi.y, lo.z));
+    add(V3(lo.x, hi.y, hi.z));
+    add(V3(hi.x, hi.y, lo.z));
+    add(V3(hi.x, hi.y, hi.z));
+    b.lo.store(out6);
+    b.hi.store(out6 + 3);
+}
+
+void orc_object_bounds(const orc_instance* I, float* out6) {
+    const float* p = I->p;
+    V3 lo(0, 0, 0), hi(0, 0, 0);
+    switch (I->geometry) {
+    case 1: // Sphere, Object.h:31-33
+        lo = V3(-p[0], -p[0], -p[0]);
+        hi = V3(p[0], p[0], p[0]);
+        break;
+    case 2: { // Rectangle, Object.h:81-92: Bounds((-u,0,-v),(u,0,v)) under the rotation with columns T, N, B
+        float rot[16] = {p[3], p[4], p[5], 0, p[0], p[1], p[2], 0, p[6], p[7], p[8], 0, 0, 0, 0, 1};
+        float obj[6] = {-p[9], 0, -p[10], p[9], 0, p[10]};
+        orc_world_bounds(obj, rot, out6);
+        return;
+    }
+    case 3: // Disk: the cube around the sphere of its outer radius (defined here; the reference has no bounds for it)
+        lo = V3(-p[3], -p[3], -p[3]);
+        hi = V3(p[3], p[3], p[3]);
+        break;
+    case 4: // Box: its own corners (defined here)
+        lo = V3(p);
+        hi = V3(p + 3);
+        break;
+    case 5: // Cylinder (defined here)
+        lo = V3(-p[0], p[1], -p[0]);
+        hi = V3(p[0], p[2], p[0]);
+        break;
+    }
+    lo.store(out6);
+    hi.store(out6 + 3);
 }
 
 void orc_look_at(const float* eye3, const float* at3, const float* up3, float* view16) { // Math.h:595-610

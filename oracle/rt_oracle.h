@@ -70,6 +70,42 @@ typedef struct orc_emissive_tri {
     float cdf;
 } orc_emissive_tri;
 
+/* ---- legacy two-level scenes: Scene::instances + tlas (Scene.cpp:6-77), Instance (Object.h:364-423)
+ * and the Geometry classes (Object.h:9-243, 266-362), in the reference's own shapes. */
+typedef struct orc_mesh { /* a Mesh + the BVH its TriangleMesh builds (Object.cpp:11-29), model space */
+    int64_t n_verts;
+    const orc_vertex* verts;
+    int64_t n_tris;
+    const orc_triangle* tris;
+    int64_t n_nodes;
+    const orc_node* nodes;
+    const int32_t* indices;
+} orc_mesh;
+
+/* geometry: 0 TriangleMesh (mesh = index into meshes), 1 Sphere (p0 radius), 2 Rectangle (p0-2 N, p3-5 T, p6-8 B, p9 u,
+ * p10 v: half side lengths), 3 Disk (p0-2 normal, p3 outer_radius, p4 inner_radius), 4 Box (p0-2 bmin, p3-5 bmax),
+ * 5 Cylinder (p0 radius, p1 ymin, p2 ymax) */
+typedef struct orc_instance {
+    int32_t geometry;
+    int32_t material;
+    int32_t mesh;
+    int32_t reserved;
+    float area; /* Geometry::area(): Rectangle (2u)(2v), everything else 0 (Object.h:18-20,121-123) */
+    float p[11];
+    float m[16];     /* model-to-world */
+    float inv_m[16]; /* world-to-model */
+} orc_instance;
+
+typedef struct orc_two_level {
+    int32_t n_instances;
+    const orc_instance* instances;
+    int32_t n_meshes;
+    const orc_mesh* meshes;
+    int64_t n_tlas_nodes; /* BVH::build(world bounds, 1, BVH_SAH), Scene.cpp:6-15 */
+    const orc_node* tlas_nodes;
+    const int32_t* tlas_indices;
+} orc_two_level;
+
 typedef struct orc_scene {
     int64_t n_verts;
     const orc_vertex* verts;
@@ -90,6 +126,9 @@ typedef struct orc_scene {
     const float* env_cdf;
     float env_total;
     float env_offset;
+    /* non-NULL: the geometry is Scene::instances under a TLAS (the legacy design) and verts/tris/nodes/indices/tri_light
+     * above are unused; lights must be rectangles (kind 0) */
+    const orc_two_level* two_level;
 } orc_scene;
 
 typedef struct orc_camera {
@@ -132,6 +171,20 @@ void orc_closest_hit(const orc_scene* s, const orc_ray* rays, int64_t n, orc_hit
 /* Scene.h:113-129 as used at main.cpp:250,281: hit with t in [0, tmax]. */
 void orc_any_hit(const orc_scene* s, const orc_ray* rays, const float* tmax, int64_t n,
                  uint8_t* occluded);
+
+/* Two-level scenes.  orc_closest_hit2 = Scene::closest_hit (Scene.cpp:17-77): index = Intersection::index (-1 on a
+ * miss); hits[i].tri = triangle index within the instance's mesh (0 for an analytic primitive), (u, v) = the triangle's
+ * bary_out.x/.y, the Rectangle's si->u/si->v (Object.h:116-117), 0 otherwise; normal3/front (optional) = si->normal and
+ * si->front_face as Instance::intersect leaves them (Object.h:389-390).  orc_any_hit2 = Scene::trace_scene as a boolean
+ * (Scene.h:113-129): the LINEAR loop over all instances, no TLAS. */
+void orc_closest_hit2(const orc_scene* s, const orc_ray* rays, int64_t n, orc_hit* hits, int32_t* index, float* normal3,
+                      uint8_t* front);
+void orc_any_hit2(const orc_scene* s, const orc_ray* rays, const float* tmax, int64_t n, uint8_t* occluded);
+/* Instance::get_world_bounds (Object.h:412-416, Math.h:800-812) of object bounds obj6 (bmin, bmax) under m. */
+void orc_world_bounds(const float* obj6, const float* m16, float* out6);
+/* Geometry::object_bounds of an analytic instance (Object.h:31-33,81-92; Box/Cylinder/Disk: defined by this build, the
+ * reference leaves them at the empty default). */
+void orc_object_bounds(const orc_instance* inst, float* out6);
 
 /* Scene.h:14-44: Camera constructor. view = column-major 16 floats. */
 void orc_camera_init(const float* view16, float fov_deg, int32_t w, int32_t h, orc_camera* out);

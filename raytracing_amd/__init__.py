@@ -34,7 +34,10 @@ FLAT_NORMALS = np.dtype([("n0", "<f4", 3), ("pad0", "<f4"), ("n1", "<f4", 3), ("
                          ("n2", "<f4", 3), ("pad2", "<f4")])
 assert RAY.itemsize == 24 and HIT.itemsize == 16 and VERTEX.itemsize == 32 and TRIANGLE.itemsize == 16
 assert NODE.itemsize == 32 and MATERIAL.itemsize == 80 and PAIR.itemsize == 64 and FLAT_TRI.itemsize == 48
-assert LIGHT.itemsize == 192 and FLAT_NORMALS.itemsize == 48
+INSTANCE = np.dtype([("geometry", "<i4"), ("material", "<i4"), ("blas_root", "<i4"), ("reserved", "<i4"), ("area", "<f4"),
+                     ("p", "<f4", 11), ("m", "<f4", 16), ("inv_m", "<f4", 16)])
+assert LIGHT.itemsize == 192 and FLAT_NORMALS.itemsize == 48 and INSTANCE.itemsize == 192
+GEO_MESH, GEO_SPHERE, GEO_RECTANGLE, GEO_DISK, GEO_BOX, GEO_CYLINDER = range(6)
 
 MAT_MATTE, MAT_GGX, MAT_BECKMANN, MAT_EMISSIVE, MAT_DISNEY_DIFFUSE, MAT_DISNEY_METAL = 0, 1, 2, 3, 4, 5
 MAT_DISNEY_CLEARCOAT, MAT_DISNEY_GLASS, MAT_ROUGH_DIELECTRIC, MAT_DISNEY_SHEEN, MAT_DISNEY_UBER, MAT_GLASS = 6, 7, 8, 9, 10, 11
@@ -43,11 +46,13 @@ FILTER_GAUSSIAN, FILTER_BOX = 0, 1
 RENDER_CLEAR, RENDER_DEVICE_OUT, RENDER_TIMING, RENDER_SERIAL = 1, 2, 4, 8
 
 (ARR_VERTS, ARR_TRIS, ARR_NODES, ARR_INDICES, ARR_MATERIALS, ARR_LIGHTS, ARR_EMISSIVE, ARR_TRI_LIGHT, ARR_ENV_RGB,
- ARR_ENV_CDF, ARR_FLAT_PAIRS, ARR_FLAT_TRIS, ARR_FLAT_NORMALS, ARR_EMISSIVE_ORIG) = range(14)
+ ARR_ENV_CDF, ARR_FLAT_PAIRS, ARR_FLAT_TRIS, ARR_FLAT_NORMALS, ARR_EMISSIVE_ORIG, ARR_TLAS_NODES, ARR_TLAS_INDICES,
+ ARR_TLAS_PAIRS, ARR_INSTANCES) = range(18)
 _ARR_DTYPES = {ARR_VERTS: VERTEX, ARR_TRIS: TRIANGLE, ARR_NODES: NODE, ARR_INDICES: np.dtype("<i4"),
                ARR_MATERIALS: MATERIAL, ARR_LIGHTS: LIGHT, ARR_EMISSIVE: EMISSIVE, ARR_TRI_LIGHT: np.dtype("<i4"),
                ARR_ENV_RGB: np.dtype("<f4"), ARR_ENV_CDF: np.dtype("<f4"), ARR_FLAT_PAIRS: PAIR,
-               ARR_FLAT_TRIS: FLAT_TRI, ARR_FLAT_NORMALS: FLAT_NORMALS, ARR_EMISSIVE_ORIG: np.dtype("<i4")}
+               ARR_FLAT_TRIS: FLAT_TRI, ARR_FLAT_NORMALS: FLAT_NORMALS, ARR_EMISSIVE_ORIG: np.dtype("<i4"),
+               ARR_TLAS_NODES: NODE, ARR_TLAS_INDICES: np.dtype("<i4"), ARR_TLAS_PAIRS: PAIR, ARR_INSTANCES: INSTANCE}
 
 
 class RtCamera(C.Structure):
@@ -76,8 +81,8 @@ class RtError(RuntimeError):
     pass
 
 
-HIP_SYMBOLS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_destroy", "rt_trace_closest",
-               "rt_trace_any", "rt_render", "rt_resolve", "rt_scene_sync"]
+HIP_SYMBOLS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_create_instanced", "rt_scene_destroy",
+               "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_render", "rt_resolve", "rt_scene_sync"]
 
 
 def load_libraries():
@@ -96,6 +101,7 @@ def load_libraries():
     hip.rt_last_error.restype = C.c_char_p
     hip.rt_device_count.restype = C.c_int
     hip.rt_trace_closest.argtypes = [vp, vp, i64, vp]
+    hip.rt_trace_closest_indexed.argtypes = [vp, vp, i64, vp, vp]
     hip.rt_trace_any.argtypes = [vp, vp, vp, i64, vp]
     hip.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtOptions), vp, C.POINTER(RtStats)]
     hip.rt_resolve.argtypes = [vp, vp, i32, i32, i32, f32, vp]
@@ -129,6 +135,16 @@ def load_libraries():
     host.rth_camera_ray.argtypes = [vp, f32, i32, i32, f32, f32, vp]
     host.rth_render_image.argtypes = [vp, vp, f32, i32, i32, i32, i32, C.c_uint32, C.c_char_p, vp, vp, C.POINTER(RtStats)]
     host.rth_scene_closest_hit.argtypes = [vp, vp, vp, vp, vp, vp]
+    host.rth_scene_new_triangle_mesh.argtypes = [vp, vp, i64, vp, i64]
+    host.rth_scene_new_triangle_mesh.restype = i32
+    host.rth_scene_add_mesh_instance.argtypes = [vp, i32, i32, vp]
+    host.rth_scene_add_mesh_instance.restype = i32
+    host.rth_scene_add_primitive_instance.argtypes = [vp, i32, vp, i32, vp, i32]
+    host.rth_scene_add_primitive_instance.restype = i32
+    host.rth_scene_mesh_array.argtypes = [vp, i32, i32, C.POINTER(i64)]
+    host.rth_scene_mesh_array.restype = vp
+    host.rth_scene_instance_bounds.argtypes = [vp, i32, vp]
+    host.rth_scene_instance_bounds.restype = i32
     host.rth_scene_any_hit.argtypes = [vp, vp]
     _hip, _host = hip, host
     return _hip, _host
@@ -211,6 +227,8 @@ class Scene:
         _, host = load_libraries()
         self._host = host
         self._h = host.rth_scene_new()
+        self.n_triangle_meshes = 0   # handles returned by new_triangle_mesh
+        self.instance_mesh = {}      # instance index -> mesh handle (mesh instances only)
 
     def close(self):
         if self._h:
@@ -242,6 +260,51 @@ class Scene:
         if len(tris) and int(tris["idx"].max()) >= len(verts):
             raise ValueError("triangle index out of range")
         self._host.rth_scene_add_instance(self._h, _ptr(verts), len(verts), _ptr(tris), len(tris), _ptr(_f32(transform16, 16)), int(material))
+
+    # ---- legacy two-level scenes: Scene::instances (Object.h:364-423).  A scene with instances is two-level: build()
+    # builds the TLAS over their world bounds (Scene.cpp:6-15) and the merged mesh is unused.
+    def new_triangle_mesh(self, verts, tris):
+        """TriangleMesh(mesh): builds the mesh's own BVH once; returns a handle for add_mesh_instance."""
+        verts = np.ascontiguousarray(verts, dtype=VERTEX)
+        tris = np.ascontiguousarray(tris, dtype=TRIANGLE)
+        if len(tris) == 0 or int(tris["idx"].max()) >= len(verts):
+            raise ValueError("empty mesh or triangle index out of range")
+        self.n_triangle_meshes += 1
+        return int(self._host.rth_scene_new_triangle_mesh(self._h, _ptr(verts), len(verts), _ptr(tris), len(tris)))
+
+    def add_mesh_instance(self, mesh, material, transform16):
+        i = self._host.rth_scene_add_mesh_instance(self._h, int(mesh), int(material), _ptr(_f32(transform16, 16)))
+        if i < 0:
+            raise ValueError("bad mesh handle or material index")
+        self.instance_mesh[i] = int(mesh)
+        return i
+
+    def add_primitive_instance(self, kind, params, material, transform16, light=False):
+        """Instance(new Sphere/Rectangle/Disk/Box/Cylinder(params), materials[material], transform); kind = GEO_*.
+        params: SPHERE (radius) | RECTANGLE (nx, ny, nz, u_length, v_length) | DISK (nx, ny, nz, outer, inner) |
+        BOX (sx, sy, sz) | CYLINDER (radius, height).  light=True also pushes it into Scene::lights (rectangles only)."""
+        p = np.zeros(8, np.float32)
+        params = np.asarray(params, np.float32).ravel()
+        p[: len(params)] = params
+        i = self._host.rth_scene_add_primitive_instance(self._h, int(kind), _ptr(p), int(material), _ptr(_f32(transform16, 16)), int(light))
+        if i < 0:
+            raise ValueError("bad geometry kind, material index, or a light that is not a rectangle")
+        return i
+
+    def mesh_array(self, mesh, which):
+        """which: 0 verts, 1 triangles, 2 BVH nodes, 3 BVH indices of a new_triangle_mesh handle."""
+        n = C.c_int64(0)
+        p = self._host.rth_scene_mesh_array(self._h, int(mesh), which, C.byref(n))
+        dt = [VERTEX, TRIANGLE, NODE, np.dtype("<i4")][which]
+        if not p or n.value == 0:
+            return np.zeros(0, dt)
+        return np.frombuffer((C.c_char * (n.value * dt.itemsize)).from_address(p), dtype=dt).copy()
+
+    def instance_bounds(self, i):
+        out = np.zeros(6, np.float32)
+        if not self._host.rth_scene_instance_bounds(self._h, int(i), _ptr(out)):
+            raise ValueError("bad instance index")
+        return out
 
     def add_material(self, rec):
         rec = np.ascontiguousarray(rec, dtype=MATERIAL)
@@ -325,6 +388,14 @@ class Scene:
         _check(_hip.rt_trace_closest(self.gpu, _ptr(rays), len(rays), _ptr(hits)))
         return hits
 
+    def trace_closest_indexed(self, rays):
+        """rt_trace_closest_indexed -> (hits, Intersection::index per ray)."""
+        rays = np.ascontiguousarray(rays, dtype=RAY)
+        hits = np.zeros(len(rays), HIT)
+        index = np.zeros(len(rays), np.int32)
+        _check(_hip.rt_trace_closest_indexed(self.gpu, _ptr(rays), len(rays), _ptr(hits), _ptr(index)))
+        return hits, index
+
     def trace_any(self, rays, tmax):
         rays = np.ascontiguousarray(rays, dtype=RAY)
         tmax = _f32(tmax, len(rays))
@@ -387,7 +458,7 @@ class Scene:
         ff = np.zeros(1, np.int32)
         if not self._host.rth_scene_closest_hit(self._h, _ptr(ray), _ptr(t), _ptr(p), _ptr(n), _ptr(ff)):
             return None
-        return {"t": float(t[0]), "point": p, "normal": n, "front_face": bool(ff[0])}
+        return {"t": float(t[0]), "point": p, "normal": n, "front_face": bool(ff[0] & 1), "index": int(ff[0] >> 1)}
 
     def any_hit(self, ray):
         ray = np.ascontiguousarray(ray, dtype=RAY).reshape(1)

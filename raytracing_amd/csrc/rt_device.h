@@ -114,6 +114,12 @@ struct SceneView {
     int32_t pend_full;  // ... or once one lane holds this many (<= RT_PEND_FULL_MAX)
     int32_t wave_min_rays; // a shard of n rays is worked on by at most ceil(n / wave_min_rays) waves
     int32_t fetch_chunk;   // rays a wave takes from its shard per cursor atomic (multiple of 64)
+    // legacy two-level scenes (inst != nullptr): TLAS records, instances, k_classify's sort key per instance
+    const float4* tl_pairs;
+    const rt_instance* inst;
+    const uint8_t* inst_type;
+    int32_t tl_root;
+    int32_t n_inst;
 };
 
 // ---- device layout of a child-pair record (64 B, repacked from rt_bvh_pair by rt_scene_create) -------------------
@@ -627,6 +633,263 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
         }
     }
     RT_STAT_FLUSH(8);
+}
+
+// ------------------------------------------------------ two-level scenes
+// Scene::closest_hit over Scene::instances (Scene.cpp:17-77): the TLAS walk; at a leaf Instance::intersect
+// (Object.h:380-394) moves the ray into model space and runs the Geometry's own test — an analytic primitive
+// (Object.h:26-243) or, for a TriangleMesh, the walk of ITS BVH (Object.h:273-344).  One loop does both levels: entering
+// a mesh swaps the lane's ray for the model-space ray and remembers the stack depth; when the stack is back at that
+// depth the mesh is finished, the world ray returns and the TLAS walk carries on.  Cull values as the reference has
+// them: the TLAS compares box distances with the closest hit over all instances (Scene.cpp:50-51), a mesh walk with the
+// closest hit found IN THIS MESH so far (Object.h:281,325-326: its local t starts infinite), while triangles are
+// accepted against the shrinking tmax handed down (Object.h:312-314).  One ray per lane, not yet the persistent
+// lane-refill scheme of trace_queue.
+#define RT_TL_LDS_STACK 16 // stack entries per lane in LDS (16 KB per 256-thread workgroup); deeper ones in private memory
+#define RT_TL_STACK_TOTAL 128 // 64 for the TLAS (Scene.cpp:19) + 64 for the mesh (Object.h:275)
+
+RT_DEV V3 xf_point(const float* m, const V3& p) { // mat4 * vec4(p, 1), Math.h:368-390
+    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.f, m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.f,
+              m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.f);
+}
+RT_DEV V3 xf_model_vector(const float* im, const V3& v) { // Transform::to_model_vector, Math.h:675-683
+    return V3(im[0] * v.x + im[4] * v.y + im[8] * v.z, im[1] * v.x + im[5] * v.y + im[9] * v.z, im[2] * v.x + im[6] * v.y + im[10] * v.z);
+}
+RT_DEV V3 xf_world_normal(const float* im, const V3& n) { // Transform::to_world_normal, Math.h:667-674
+    return V3(im[0] * n.x + im[1] * n.y + im[2] * n.z, im[4] * n.x + im[5] * n.y + im[6] * n.z, im[8] * n.x + im[9] * n.y + im[10] * n.z);
+}
+
+struct Hit2 {
+    float t, u, v;
+    int slot;     // >= 0: triangle slot of a mesh instance; -2: analytic primitive; -1: nothing
+    int inst;
+    V3 n;         // analytic primitive: model-space normal after set_face_normal / set_forward_face
+    bool front;   // ... and its front_face
+};
+
+RT_DEV float comp(const V3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+
+// Geometry::intersect of the analytic primitives with the ray in model space.  (o, d, tmin, tmax) as the reference
+// passes them; on a hit t, n (oriented), front, u, v are set.  Comparisons the reference writes against double
+// constants are made in double.
+RT_DEV bool prim_intersect(const rt_instance& I, const V3& o, const V3& d, float tmin, float tmax, Hit2* h) {
+    const float* p = I.p;
+    switch (I.geometry) {
+    case RT_GEO_SPHERE: { // Object.h:34-55
+        const float radius = p[0];
+        const float a = dot(d, d);
+        const float halfb = dot(o, d);
+        const float c = dot(o, o) - radius * radius;
+        const float disc = halfb * halfb - a * c;
+        if (disc < 0.f) return false;
+        const float sq = sqrtf(disc);
+        float root = (-halfb - sq) / a;
+        if (root < tmin || root > tmax) {
+            root = (-halfb + sq) / a;
+            if (root < tmin || root > tmax) return false;
+        }
+        const V3 out = (o + d * root) / radius;
+        h->t = root;
+        h->front = dot(d, out) < 0.f;
+        h->n = h->front ? out : -out;
+        h->u = h->v = 0.f;
+        return true;
+    }
+    case RT_GEO_RECTANGLE: { // Object.h:93-120
+        const V3 N(p), T(p + 3), B(p + 6);
+        const float denom = dot(N, d);
+        if ((double)fabsf(denom) < 0.01) return false;
+        const float dist = dot(o, N);
+        const float t = -dist / denom;
+        if (t < tmin || t > tmax) return false;
+        const V3 pi = o + d * t;
+        const float ud = dot(pi, T);
+        if (ud < -p[9] || ud > p[9]) return false;
+        const float vd = dot(pi, B);
+        if (vd < -p[10] || vd > p[10]) return false;
+        h->t = t;
+        h->front = dot(d, N) < 0.f;
+        h->n = h->front ? N : -N;
+        h->u = ud / p[9];
+        h->v = vd / p[10];
+        return true;
+    }
+    case RT_GEO_DISK: { // Object.h:141-162
+        const V3 N(p);
+        const float denom = dot(N, d);
+        if ((double)fabsf(denom) < 0.01) return false;
+        const float dist = dot(o, N);
+        const float t = -dist / denom;
+        if (t < tmin || t > tmax) return false;
+        const float r = len(o + d * t);
+        if (r > p[3] || r < p[4]) return false;
+        h->t = t;
+        h->front = dot(d, N) < 0.f;
+        h->n = h->front ? N : -N;
+        h->u = h->v = 0.f;
+        return true;
+    }
+    case RT_GEO_BOX: { // Object.h:175-204
+        float gm = -INFINITY;
+        int idx = 0;
+        for (int a = 0; a < 3; a++) {
+            const float oa = comp(o, a), da = comp(d, a);
+            const float x0 = (p[a] - oa) / da, x1 = (p[3 + a] - oa) / da;
+            const float t0 = fminf(x0, x1), t1 = fmaxf(x0, x1);
+            tmin = fmaxf(t0, tmin);
+            tmax = fminf(t1, tmax);
+            if (tmax <= tmin) return false;
+            if (tmin > gm) {
+                gm = tmin;
+                idx = a;
+            }
+        }
+        const float s = comp(d, idx) > 0.f ? -1.f : 1.f;
+        const V3 out(idx == 0 ? s : 0.f, idx == 1 ? s : 0.f, idx == 2 ? s : 0.f);
+        h->t = gm;
+        h->front = dot(d, out) < 0.f;
+        h->n = h->front ? out : -out;
+        h->u = h->v = 0.f;
+        return true;
+    }
+    case RT_GEO_CYLINDER: { // Object.h:216-239
+        const float radius = p[0], ymin = p[1], ymax = p[2];
+        const float a = d.x * d.x + d.z * d.z;
+        const float b = 2.f * (o.x * d.x + o.z * d.z);
+        const float c = o.x * o.x + o.z * o.z - radius * radius;
+        const float disc = b * b - 4.f * a * c;
+        if (disc < 0.f) return false;
+        const float sq = sqrtf(disc);
+        float root = (-b - sq) / (2.f * a);
+        V3 pt = o + d * root;
+        if (root < tmin || root > tmax || pt.y < ymin || pt.y > ymax) {
+            root = (-b + sq) / (2.f * a);
+            pt = o + d * root;
+            if (root < tmin || root > tmax || pt.y < ymin || pt.y > ymax) return false;
+        }
+        const V3 out = V3(pt.x, 0.f, pt.z) / radius;
+        h->t = root;
+        h->n = dot(d, out) < 0.f ? out : -out; // set_forward_face, Def.h:35-39
+        h->front = true;
+        h->u = h->v = 0.f;
+        return true;
+    }
+    default: return false;
+    }
+}
+
+// ANY = false: closest hit (h filled, returns whether anything was hit).  ANY = true: is anything hit with
+// t in [0, tmax_in] (Scene::trace_scene as a boolean, Scene.h:113-129) — boxes entered beyond the segment's end plus
+// the margin of occlusion_queue are skipped at both levels, and the walk ends at the first accepted hit.
+// lds = this lane's column of the workgroup's stack (stride RT_BLOCK).
+template <bool ANY>
+RT_DEV bool walk_two_level(const SceneView& sc, lds_int* lds, const V3& o, const V3& d, float tmax_in, Hit2* h) {
+    int spill[RT_TL_STACK_TOTAL - RT_TL_LDS_STACK];
+    h->slot = -1;
+    h->inst = -1;
+    h->t = INFINITY;
+    h->u = h->v = 0.f;
+    h->n = V3(0.f);
+    h->front = true;
+    if (sc.n_inst <= 0) return false;
+    float t_best = ANY ? tmax_in : INFINITY; // closest_so_far / Scene::closest_hit's t
+    float t_local = INFINITY;                // TriangleMesh::intersect's own t
+    const float tcull = (tmax_in > 0.f && tmax_in < INFINITY) ? tmax_in * 1.0001f + 0.000001f : (tmax_in <= 0.f ? tmax_in : INFINITY);
+    bool found = false;
+    bool dummy;
+    const RaySlab world = ray_slab(pack(o, 0.f), pack(d, 0.f), &dummy);
+    RaySlab rs = world;
+    V3 co = o, cd = d;
+    int sp = 0, base = -1, cur_inst = -1; // base >= 0: inside a mesh instance, entered at this stack depth
+    int cur = sc.tl_root;
+    for (;;) {
+        bool pop = false;
+        if (cur >= 0) { // inner node of the current level (Scene.cpp:47-68 / Object.h:322-343)
+            const f4* p = (const f4*)((const char*)(base >= 0 ? sc.pairs : sc.tl_pairs) + (uint32_t)cur);
+            const f4 q0 = p[0], q1 = p[1], q2 = p[2];
+            const unsigned long long rr = *(const unsigned long long*)(p + 3);
+            const int lref = (int)(uint32_t)rr, rref = (int)(uint32_t)(rr >> 32);
+            float ld, rd;
+            bool lh, rh;
+            slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
+            const float cull = ANY ? tcull : (base >= 0 ? t_local : t_best);
+            lh = lh && ld < cull;
+            rh = rh && rd < cull;
+            const bool left_first = ld < rd;
+            cur = (lh && (!rh || left_first)) ? lref : rref;
+            if (lh && rh) {
+                const int far = left_first ? rref : lref;
+                if (sp < RT_TL_LDS_STACK) lds[sp * RT_BLOCK] = far;
+                else if (sp < RT_TL_STACK_TOTAL) spill[sp - RT_TL_LDS_STACK] = far;
+                if (sp < RT_TL_STACK_TOTAL) sp++; // (a tree deeper than the reference's own stacks loses the entry, never memory)
+            } else if (!lh && !rh) {
+                pop = true;
+            }
+        } else if (base >= 0) { // leaf of the mesh's BVH (Object.h:292-320)
+            int slot = ~cur;
+            bool last;
+            do {
+                float4 a, b, c;
+                load_tri(sc.tris, slot, a, b, c);
+                last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
+                float tt, u, v;
+                if (tri_accept(co, cd, a, b, c, t_best, &tt, &u, &v)) {
+                    if (ANY) return true;
+                    t_best = tt;
+                    t_local = tt;
+                    found = true;
+                    h->t = tt;
+                    h->u = u;
+                    h->v = v;
+                    h->slot = slot;
+                    h->inst = cur_inst;
+                }
+                slot++;
+            } while (!last);
+            pop = true;
+        } else { // TLAS leaf: one Instance (Scene.cpp:33-44, Object.h:380-394)
+            const int k = ~cur;
+            const rt_instance& I = sc.inst[k];
+            const V3 mo = xf_point(I.inv_m, o), md = xf_model_vector(I.inv_m, d); // Transform::to_model_ray, Math.h:692-694
+            if (I.geometry == RT_GEO_MESH) {
+                base = sp;
+                cur_inst = k;
+                co = mo;
+                cd = md;
+                rs = ray_slab(pack(mo, 0.f), pack(md, 0.f), &dummy);
+                t_local = INFINITY;
+                cur = I.blas_root; // (a one-leaf mesh: its root is never box-tested, Object.h:276-290)
+                continue;
+            }
+            Hit2 g;
+            if (prim_intersect(I, mo, md, 0.f, t_best, &g)) {
+                if (ANY) return true;
+                t_best = g.t;
+                found = true;
+                h->t = g.t;
+                h->u = g.u;
+                h->v = g.v;
+                h->n = g.n;
+                h->front = g.front;
+                h->slot = -2;
+                h->inst = k;
+            }
+            pop = true;
+        }
+        if (pop) {
+            if (base >= 0 && sp == base) { // the mesh is finished: back to the world ray and the TLAS
+                base = -1;
+                co = o;
+                cd = d;
+                rs = world;
+            }
+            if (sp == 0) break;
+            sp--;
+            if (sp < RT_TL_LDS_STACK) cur = lds[sp * RT_BLOCK];
+            else cur = spill[sp - RT_TL_LDS_STACK];
+        }
+    }
+    return found;
 }
 
 // ---------------------------------------------------------------- shading

@@ -52,6 +52,7 @@ struct Wave {
     float4* q_o[2];   // origin.xyz, path id (bits)
     float4* q_d[2];   // dir.xyz, unused
     float4* hit;      // slot (bits), t, u, v
+    float4* hit2;     // two-level scenes only: analytic primitive's oriented model-space normal, instance | front_face << 30 (bits)
     // path state, indexed by path id: ONE 64-byte record per path (a queue entry's path id is random, so every access
     // is its own HBM sector: three 16-byte arrays cost three sectors per read and three partial-line writes)
     //   [0] throughput.xyz, scatter_pdf   [1] radiance.xyz, rng key (bits)   [2] prev.point.xyz, rng counter (bits)   [3] spare
@@ -156,6 +157,38 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float
                     top_bytes, [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
 
+// ---- two-level scenes (rt_scene_create_instanced): one ray per lane over the same sharded queues
+#define RT_HIT2_FRONT 0x40000000
+RT_DEV bool tl_queue_entry(const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap, uint32_t j) {
+    const uint32_t shard = j / shard_cap;
+    return shard < n_shards && j - shard * shard_cap < counts[(size_t)shard * RT_CSTRIDE];
+}
+__global__ __launch_bounds__(RT_BLOCK) void k_closest2(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                  const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
+                                                  float4* __restrict__ hit, float4* __restrict__ hit2, int want_tri_id) {
+    __shared__ int stack[RT_TL_LDS_STACK * RT_BLOCK];
+    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (!tl_queue_entry(counts, n_shards, shard_cap, j)) return;
+    Hit2 h;
+    walk_two_level<false>(sc, (lds_int*)stack + threadIdx.x, V3(q_o[j]), V3(q_d[j]), INFINITY, &h);
+    int slot = h.slot;
+    if (want_tri_id && slot != -1) slot = slot >= 0 ? (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END) : 0;
+    hit[j] = make_float4(__int_as_float(slot), h.t, h.u, h.v);
+    hit2[j] = pack(h.n, __int_as_float(h.inst < 0 ? -1 : (h.inst | (h.front ? RT_HIT2_FRONT : 0))));
+}
+// out[j] = on_hit when something blocks the segment (tmax = origin.w), 1 - on_hit otherwise
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow2(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
+                                                 const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
+                                                 uint8_t* __restrict__ out, int on_hit) {
+    __shared__ int stack[RT_TL_LDS_STACK * RT_BLOCK];
+    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (!tl_queue_entry(counts, n_shards, shard_cap, j)) return;
+    const float4 o4 = s_o[j];
+    Hit2 h;
+    const bool occluded = walk_two_level<true>(sc, (lds_int*)stack + threadIdx.x, V3(o4), V3(s_d[j]), o4.w, &h);
+    out[j] = (uint8_t)(occluded ? on_hit : 1 - on_hit);
+}
+
 // wave64 compaction over the lanes that call it (under divergence: the lanes of the current branch): ONE atomic per
 // wave reserves, for every calling lane, `per_lane` entries plus one more for lanes with `extra`; returns the calling
 // lane's first entry.  Entries of one lane are contiguous, lanes in lane order.
@@ -226,6 +259,7 @@ __device__ unsigned long long g_shade_stats[256 * 32];
 // cost of this kernel), then walks its groups again and writes the indices.
 RT_DEV int classify_key(const SceneView& sc, const Wave& w, uint32_t q) {
     const int slot = __float_as_int(w.hit[q].x);
+    if (sc.inst) return slot == -1 ? RT_KEY_MISS : (int)sc.inst_type[__float_as_int(w.hit2[q].w) & (RT_HIT2_FRONT - 1)];
     return slot < 0 ? RT_KEY_MISS : (int)sc.tri_type[slot];
 }
 __global__ __launch_bounds__(RT_BLOCK) void k_classify(SceneView sc, Wave w, PassParams pp, int bounce) {
@@ -279,7 +313,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_classify(SceneView sc, Wave w, Pas
 
 // Shades queue entry q whose hit has material type KEY.  Runs under divergence; wave_reserve() compacts over the
 // lanes that reach it, which is all a dense queue needs.  The workgroup appends to output shard `out_shard`.
-template <int KEY, class TB>
+template <int KEY, bool TL, class TB>
 RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const PassParams& pp, int bounce, int last_bounce, uint32_t q, uint32_t out_shard) {
     SH_T0
     const int in = bounce & 1, out = in ^ 1;
@@ -306,18 +340,44 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
         SH_MARK(1); // miss: environment lookup
         return;
     }
-    // TriangleMesh::intersect tail, Object.h:350-355
-    // the device copy of the normals record carries the triangle's material and light index in its pad words, so
-    // shading reads one 48-byte record per hit (every divergent load instruction costs 64 L1 look-ups)
-    const float4* nq = sc.normals + 3 * (size_t)slot;
-    const float4 n0 = nq[0], n1 = nq[1], n2 = nq[2];
-    const int mat_id = __float_as_int(n0.w), light_id = __float_as_int(n1.w);
     Surf si;
-    si.point = ro + rd * h4.y;
-    V3 N = (1.f - h4.z - h4.w) * V3(n0) + h4.z * V3(n1) + h4.w * V3(n2);
-    N = normalize(N);
-    si.front_face = dot(rd, N) < 0.f;
-    si.normal = si.front_face ? N : -N;
+    int mat_id;
+    float hit_area; // world.instances[si.index].get_area() of main.cpp:376
+    if (TL) { // Instance::intersect, Object.h:380-394: the Geometry's answer in model space, then point and normal to world
+        const float4 g4 = w.hit2[q];
+        const int iw = __float_as_int(g4.w);
+        const rt_instance& I = sc.inst[iw & (RT_HIT2_FRONT - 1)];
+        const V3 mo = xf_point(I.inv_m, ro), md = xf_model_vector(I.inv_m, rd);
+        V3 nm;
+        if (slot >= 0) { // TriangleMesh::intersect tail, Object.h:350-355
+            const float4* nq = sc.normals + 3 * (size_t)slot;
+            V3 N = (1.f - h4.z - h4.w) * V3(nq[0]) + h4.z * V3(nq[1]) + h4.w * V3(nq[2]);
+            N = normalize(N);
+            si.front_face = dot(md, N) < 0.f;
+            nm = si.front_face ? N : -N;
+        } else {
+            nm = V3(g4);
+            si.front_face = (iw & RT_HIT2_FRONT) != 0;
+        }
+        si.point = xf_point(I.m, mo + md * h4.y);
+        si.normal = normalize(xf_world_normal(I.inv_m, nm));
+        mat_id = I.material;
+        hit_area = I.area;
+    } else {
+        // TriangleMesh::intersect tail, Object.h:350-355
+        // the device copy of the normals record carries the triangle's material and light index in its pad words, so
+        // shading reads one 48-byte record per hit (every divergent load instruction costs 64 L1 look-ups)
+        const float4* nq = sc.normals + 3 * (size_t)slot;
+        const float4 n0 = nq[0], n1 = nq[1], n2 = nq[2];
+        mat_id = __float_as_int(n0.w);
+        const int light_id = __float_as_int(n1.w);
+        si.point = ro + rd * h4.y;
+        V3 N = (1.f - h4.z - h4.w) * V3(n0) + h4.z * V3(n1) + h4.w * V3(n2);
+        N = normalize(N);
+        si.front_face = dot(rd, N) < 0.f;
+        si.normal = si.front_face ? N : -N;
+        hit_area = light_id >= 0 ? sc.lights[light_id].area : 0.f; // Geometry::area() default, Object.h:18-20
+    }
     rt_material mat = sc.materials[mat_id];
     mat.type = KEY; // compile-time constant: the material switches below fold to this kernel's one case
 
@@ -330,8 +390,7 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
     float weight = 1.f;
     if (bounce > 0 && dot(emitted, V3(1.0f)) > 0.1f) { // main.cpp:373-396
         float cos_light = fmax_sel(dot(rd, -si.normal), 0.f);
-        float area = light_id >= 0 ? sc.lights[light_id].area : 0.f; // Geometry::area() default, Object.h:18-20
-        float denom = area * cos_light;
+        float denom = hit_area * cos_light;
         if (denom <= 0.f || !si.front_face) {
             weight = 0.f;
         } else {
@@ -423,7 +482,7 @@ struct ShadeOrder { // the shading kernels of a bounce in launch order
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 1
 #endif
-template <int KEY>
+template <int KEY, bool TL>
 __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView sc_in, Wave w, PassParams pp, ShadeOrder order, int bounce, int last_bounce) {
     // The sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox) and the environment is read
     // with four bilinear taps: from LDS when all the tables fit (wave-uniform choice between two instantiations).
@@ -460,7 +519,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView 
         for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) { // persistent, grid-stride
             const uint32_t i = base + threadIdx.x;
             const uint32_t out_shard = (group0 + base / RT_BLOCK) % pp.n_shards;
-            if (i < n) shade_item<KEY>(sc, tb, w, pp, bounce, last_bounce, perm[i], out_shard);
+            if (i < n) shade_item<KEY, TL>(sc, tb, w, pp, bounce, last_bounce, perm[i], out_shard);
         }
     } else {
         GlobalTables tb;
@@ -470,7 +529,7 @@ __global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView 
         for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
             const uint32_t i = base + threadIdx.x;
             const uint32_t out_shard = (group0 + base / RT_BLOCK) % pp.n_shards;
-            if (i < n) shade_item<KEY>(sc, tb, w, pp, bounce, last_bounce, perm[i], out_shard);
+            if (i < n) shade_item<KEY, TL>(sc, tb, w, pp, bounce, last_bounce, perm[i], out_shard);
         }
     }
 }
@@ -602,6 +661,8 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
         if ((rc = wave_alloc(s, &w.q_d[i], c))) return rc;
     }
     if ((rc = wave_alloc(s, &w.hit, c))) return rc;
+    w.hit2 = nullptr;
+    if (s->view.inst && (rc = wave_alloc(s, &w.hit2, c))) return rc;
     if ((rc = wave_alloc(s, &w.path, 4 * c))) return rc;
     if ((rc = wave_alloc(s, &w.s_c, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_T, kc))) return rc;
@@ -625,8 +686,11 @@ static void launch_shade(rt_scene* s, hipStream_t st, const Wave& wave, int key,
     ShadeOrder order{};
     order.n = (int32_t)s->keys.size();
     for (size_t i = 0; i < s->keys.size(); i++) order.keys[i] = s->keys[i];
-#define RT_SHADE_CASE(K) \
-    case K: hipLaunchKernelGGL(k_shade_t<K>, g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce); break;
+#define RT_SHADE_CASE(K)                                                                                           \
+    case K:                                                                                                        \
+        if (s->view.inst) hipLaunchKernelGGL((k_shade_t<K, true>), g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce); \
+        else hipLaunchKernelGGL((k_shade_t<K, false>), g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce);  \
+        break;
     switch (key) {
         RT_SHADE_CASE(0) RT_SHADE_CASE(1) RT_SHADE_CASE(2) RT_SHADE_CASE(3) RT_SHADE_CASE(4) RT_SHADE_CASE(5) RT_SHADE_CASE(6)
         RT_SHADE_CASE(7) RT_SHADE_CASE(8) RT_SHADE_CASE(9) RT_SHADE_CASE(10) RT_SHADE_CASE(11) RT_SHADE_CASE(12)
@@ -646,10 +710,12 @@ int rt_device_count(void) {
     return n;
 }
 
-int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
+// tl == nullptr: the flat scene of rt_scene_create; otherwise the two-level scene of rt_scene_create_instanced
+static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int device, rt_scene** out) {
     if (!d || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
     *out = nullptr;
-    if (d->n_tris <= 0 || !d->tris || !d->normals) return fail(RT_ERR_INVALID, "rt_scene_create: scene has no triangles");
+    if (!tl && d->n_tris <= 0) return fail(RT_ERR_INVALID, "rt_scene_create: scene has no triangles");
+    if (d->n_tris < 0 || (d->n_tris > 0 && (!d->tris || !d->normals))) return fail(RT_ERR_INVALID, "rt_scene_create: bad triangle table");
     if (d->n_pairs < 0 || (d->n_pairs > 0 && !d->pairs)) return fail(RT_ERR_INVALID, "rt_scene_create: bad pair table");
     if (d->n_pairs > RT_MAX_PAIRS) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^25 - 1 child-pair records");
     if (d->n_tris > (int64_t)0xffffffffu / 48) return fail(RT_ERR_LIMIT, "rt_scene_create: more than 89 million triangles");
@@ -657,18 +723,39 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (d->n_materials <= 0 || !d->materials) return fail(RT_ERR_INVALID, "rt_scene_create: no materials");
     // every reference a kernel will follow is checked here, on the host, so that a bad
     // description is an error code and not a GPU memory fault
-    if (d->root_ref >= 0 ? d->root_ref >= d->n_pairs : ~d->root_ref >= d->n_tris)
+    if (!tl && (d->root_ref >= 0 ? d->root_ref >= d->n_pairs : ~d->root_ref >= d->n_tris))
         return fail(RT_ERR_INVALID, "rt_scene_create: root_ref out of range");
     for (int64_t i = 0; i < d->n_pairs; i++) {
         const int32_t refs[2] = {d->pairs[i].lref, d->pairs[i].rref};
         for (int32_t r : refs)
             if (r >= 0 ? r >= d->n_pairs : ~r >= d->n_tris) return fail(RT_ERR_INVALID, "rt_scene_create: child ref out of range");
     }
-    if (!(d->tris[d->n_tris - 1].tri_id & RT_TRI_LEAF_END)) return fail(RT_ERR_INVALID, "rt_scene_create: last triangle must end a leaf");
-    for (int64_t i = 0; i < d->n_tris; i++) {
+    if (d->n_tris > 0 && !(d->tris[d->n_tris - 1].tri_id & RT_TRI_LEAF_END))
+        return fail(RT_ERR_INVALID, "rt_scene_create: last triangle must end a leaf");
+    for (int64_t i = 0; i < d->n_tris && !tl; i++) {
         if (d->tris[i].material < 0 || d->tris[i].material >= d->n_materials)
             return fail(RT_ERR_INVALID, "rt_scene_create: triangle material out of range");
         if (d->tris[i].light >= d->n_lights) return fail(RT_ERR_INVALID, "rt_scene_create: triangle light out of range");
+    }
+    if (tl) {
+        if (tl->n_instances <= 0 || !tl->instances) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: no instances");
+        if (tl->n_instances >= RT_HIT2_FRONT) return fail(RT_ERR_LIMIT, "rt_scene_create_instanced: more than 2^30 - 1 instances");
+        if (tl->n_pairs < 0 || (tl->n_pairs > 0 && !tl->pairs) || tl->n_pairs > RT_MAX_PAIRS)
+            return fail(RT_ERR_INVALID, "rt_scene_create_instanced: bad TLAS pair table");
+        auto tl_ref_ok = [&](int32_t r) { return r >= 0 ? r < tl->n_pairs : ~r < tl->n_instances; };
+        if (!tl_ref_ok(tl->root_ref)) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: TLAS root_ref out of range");
+        for (int64_t i = 0; i < tl->n_pairs; i++)
+            if (!tl_ref_ok(tl->pairs[i].lref) || !tl_ref_ok(tl->pairs[i].rref))
+                return fail(RT_ERR_INVALID, "rt_scene_create_instanced: TLAS child ref out of range");
+        for (int32_t i = 0; i < tl->n_instances; i++) {
+            const rt_instance& I = tl->instances[i];
+            if (I.geometry < RT_GEO_MESH || I.geometry > RT_GEO_CYLINDER) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: unknown geometry");
+            if (I.material < 0 || I.material >= d->n_materials) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: instance material out of range");
+            if (I.geometry == RT_GEO_MESH && (I.blas_root >= 0 ? I.blas_root >= d->n_pairs : ~I.blas_root >= d->n_tris))
+                return fail(RT_ERR_INVALID, "rt_scene_create_instanced: blas_root out of range");
+        }
+        for (int32_t i = 0; i < d->n_lights; i++)
+            if (d->lights[i].kind != RT_LIGHT_RECT) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: lights must be rectangles");
     }
     for (int32_t i = 0; i < d->n_materials; i++)
         if (d->materials[i].type < 0 || d->materials[i].type >= RT_KEY_MISS) return fail(RT_ERR_INVALID, "rt_scene_create: unknown material type");
@@ -730,12 +817,12 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     const rt_bvh_pair* pairs;
     const rt_tri* tris;
     const rt_tri_normals* normals;
-    {
-        // device layout of the pair records (rt_device.h): bounds regrouped for packed arithmetic, inner refs as byte offsets
-        std::vector<rt_bvh_pair> dev((size_t)d->n_pairs);
+    // device layout of the pair records (rt_device.h): bounds regrouped for packed arithmetic, inner refs as byte offsets
+    auto upload_pairs = [&](const rt_bvh_pair* src, int64_t n, const rt_bvh_pair** dst) {
+        std::vector<rt_bvh_pair> dev((size_t)n);
         auto ref = [](int32_t r) { return r >= 0 ? r * RT_PAIR_BYTES : r; };
-        for (int64_t i = 0; i < d->n_pairs; i++) {
-            const rt_bvh_pair& p = d->pairs[i];
+        for (int64_t i = 0; i < n; i++) {
+            const rt_bvh_pair& p = src[i];
             float* f = (float*)&dev[(size_t)i];
             const float q[12] = {p.lmin[0], p.lmin[1], p.lmax[0], p.lmax[1], p.rmin[0], p.rmin[1], p.rmax[0], p.rmax[1],
                                  p.lmin[2], p.rmin[2], p.lmax[2], p.rmax[2]};
@@ -743,16 +830,19 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             const int32_t refs[4] = {ref(p.lref), ref(p.rref), 0, 0};
             std::memcpy(f + 12, refs, sizeof(refs));
         }
-        if ((rc = upload(s, dev.data(), (size_t)d->n_pairs, &pairs))) return bail(rc);
-    }
+        return upload(s, dev.data(), (size_t)n, dst);
+    };
+    if ((rc = upload_pairs(d->pairs, d->n_pairs, &pairs))) return bail(rc);
     if ((rc = upload(s, d->tris, (size_t)d->n_tris, &tris))) return bail(rc);
-    {
+    if (d->n_tris > 0) {
         std::vector<rt_tri_normals> dev(d->normals, d->normals + d->n_tris);
         for (int64_t i = 0; i < d->n_tris; i++) { // pad words of the device copy: the triangle's material and light index
             std::memcpy(&dev[(size_t)i].pad0, &d->tris[i].material, 4);
             std::memcpy(&dev[(size_t)i].pad1, &d->tris[i].light, 4);
         }
         if ((rc = upload(s, dev.data(), (size_t)d->n_tris, &normals))) return bail(rc);
+    } else {
+        normals = nullptr;
     }
     if ((rc = upload(s, d->materials, (size_t)d->n_materials, &s->view.materials))) return bail(rc);
     if ((rc = upload(s, d->lights, (size_t)d->n_lights, &s->view.lights))) return bail(rc);
@@ -765,7 +855,29 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         s->view.env_total = d->env_total;
         s->view.env_offset = d->env_offset;
     }
-    {
+    if (tl) {
+        // two-level scene: TLAS records (leaf ref = ~instance), instances with blas_root in the device's ref encoding,
+        // k_classify's sort key per instance
+        const rt_bvh_pair* tl_pairs;
+        if ((rc = upload_pairs(tl->pairs, tl->n_pairs, &tl_pairs))) return bail(rc);
+        std::vector<rt_instance> inst(tl->instances, tl->instances + tl->n_instances);
+        std::vector<uint8_t> inst_type((size_t)tl->n_instances);
+        int64_t per_type[RT_N_KEYS] = {};
+        for (int32_t i = 0; i < tl->n_instances; i++) {
+            if (inst[(size_t)i].blas_root >= 0) inst[(size_t)i].blas_root *= RT_PAIR_BYTES;
+            inst_type[(size_t)i] = (uint8_t)d->materials[inst[(size_t)i].material].type;
+            per_type[inst_type[(size_t)i]]++;
+        }
+        if ((rc = upload(s, inst.data(), inst.size(), &s->view.inst))) return bail(rc);
+        if ((rc = upload(s, inst_type.data(), inst_type.size(), &s->view.inst_type))) return bail(rc);
+        s->view.tl_pairs = (const float4*)tl_pairs;
+        s->view.tl_root = tl->root_ref >= 0 ? tl->root_ref * RT_PAIR_BYTES : tl->root_ref;
+        s->view.n_inst = tl->n_instances;
+        for (int k = 0; k < RT_KEY_MISS; k++)
+            if (per_type[k]) s->keys.push_back(k);
+        std::sort(s->keys.begin(), s->keys.end(), [&](int a, int b) { return per_type[a] > per_type[b]; });
+        s->keys.push_back(RT_KEY_MISS);
+    } else {
         // k_classify's sort key per triangle slot, and the list of shading kernels this scene needs
         std::vector<uint8_t> tri_type((size_t)d->n_tris);
         int64_t per_type[RT_N_KEYS] = {};
@@ -796,7 +908,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (const char* e = getenv("RT_TUNE_WAVE_MIN")) s->view.wave_min_rays = std::max(0, atoi(e));
     if (const char* e = getenv("RT_TUNE_FETCH_CHUNK")) s->view.fetch_chunk = std::max(64, atoi(e) / 64 * 64);
     s->view.n_lights = d->n_lights;
-    s->view.n_emissive = d->n_emissive_tris;
+    s->view.n_emissive = tl ? 0 : d->n_emissive_tris;
     s->view.n_pairs = (int32_t)std::min<int64_t>(d->n_pairs, 0x7fffffff);
     s->n_pairs = d->n_pairs;
     s->n_tris = d->n_tris;
@@ -804,6 +916,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->n_lights = d->n_lights;
     *out = s;
     return RT_OK;
+}
+
+int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) { return scene_create(d, nullptr, device, out); }
+
+int rt_scene_create_instanced(const rt_scene_desc* d, const rt_tlas_desc* tlas, int device, rt_scene** out) {
+    if (!tlas) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: null TLAS description");
+    return scene_create(d, tlas, device, out);
 }
 
 void rt_scene_destroy(rt_scene* s) {
@@ -835,7 +954,7 @@ int rt_scene_sync(rt_scene* s) {
     return RT_OK;
 }
 
-static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, rt_hit* hits, uint8_t* occ) {
+static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, rt_hit* hits, uint8_t* occ, int32_t* index = nullptr) {
     if (!s || !rays || n < 0 || (!hits && !occ)) return fail(RT_ERR_INVALID, "rt_trace: bad argument");
     if (n == 0) return RT_OK;
     if (n > 0x7fffffff) return fail(RT_ERR_LIMIT, "rt_trace: more than 2^31-1 rays in one call");
@@ -845,14 +964,16 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
         o[i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], tmax ? tmax[i] : INFINITY);
         d[i] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], 0.f);
     }
-    float4 *d_o = nullptr, *d_d = nullptr, *d_hit = nullptr;
+    float4 *d_o = nullptr, *d_d = nullptr, *d_hit = nullptr, *d_hit2 = nullptr;
     uint8_t* d_occ = nullptr;
+    const bool two_level = s->view.inst != nullptr;
     uint32_t* d_count = nullptr;
     int rc = RT_OK;
     auto cleanup = [&]() {
         (void)hipFree(d_o);
         (void)hipFree(d_d);
         (void)hipFree(d_hit);
+        (void)hipFree(d_hit2);
         (void)hipFree(d_occ);
         (void)hipFree(d_count);
     };
@@ -878,10 +999,19 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
     if (hits) {
         TRY(hipMalloc((void**)&d_hit, (size_t)n * sizeof(float4)));
-        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
-                           (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, 1);
-        TRY(hipGetLastError());
-        std::vector<float4> h((size_t)n);
+        std::vector<float4> h((size_t)n), h2;
+        if (two_level) {
+            TRY(hipMalloc((void**)&d_hit2, (size_t)n * sizeof(float4)));
+            hipLaunchKernelGGL(k_closest2, dim3(blocks_for(piece * RT_SHARDS)), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count,
+                               (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, d_hit2, 1);
+            TRY(hipGetLastError());
+            h2.resize((size_t)n);
+            TRY(hipMemcpyAsync(h2.data(), d_hit2, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        } else {
+            hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                               (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, 1);
+            TRY(hipGetLastError());
+        }
         TRY(hipMemcpyAsync(h.data(), d_hit, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
         TRY(hipStreamSynchronize(s->stream));
         for (int64_t i = 0; i < n; i++) {
@@ -891,11 +1021,23 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
             hits[i].t = h[i].y;
             hits[i].u = h[i].z;
             hits[i].v = h[i].w;
+            if (index) {
+                int32_t iw = tri < 0 ? -1 : 0;
+                if (two_level) {
+                    std::memcpy(&iw, &h2[i].w, 4);
+                    if (iw >= 0) iw &= RT_HIT2_FRONT - 1;
+                }
+                index[i] = iw;
+            }
         }
     } else {
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
-        hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
-                           (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ);
+        if (two_level)
+            hipLaunchKernelGGL(k_shadow2, dim3(blocks_for(piece * RT_SHARDS)), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count,
+                               (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ, 1);
+        else
+            hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                               (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ);
         TRY(hipGetLastError());
         TRY(hipMemcpyAsync(occ, d_occ, (size_t)n, hipMemcpyDeviceToHost, s->stream));
         TRY(hipStreamSynchronize(s->stream));
@@ -906,6 +1048,11 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
 }
 
 int rt_trace_closest(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit* hits) { return trace_common(s, rays, nullptr, n, hits, nullptr); }
+
+int rt_trace_closest_indexed(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit* hits, int32_t* index) {
+    if (!hits) return fail(RT_ERR_INVALID, "rt_trace_closest_indexed: hits is null");
+    return trace_common(s, rays, nullptr, n, hits, nullptr, index);
+}
 
 int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occluded) {
     if (!tmax) return fail(RT_ERR_INVALID, "rt_trace_any: tmax is null");
@@ -932,6 +1079,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     const int64_t capq = shard_cap * RT_SHARDS;
     if (cap > (int64_t)1 << 30) return fail(RT_ERR_LIMIT, "rt_render: more than 2^30 paths per pass; lower spp_per_pass");
     const bool has_env = s->view.env_rgb != nullptr;
+    const bool two_level = s->view.inst != nullptr;
     const int K = (has_env ? 1 : 0) + s->n_lights;
     const int n_pass = (o->spp_count + spp_pass - 1) / spp_pass;
     // Sample passes are independent until their sums are added to the frame: with two or more, pass i runs on
@@ -1023,15 +1171,22 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
             uint32_t* ray_counts = wave.counts + (size_t)b * RT_SHARDS * RT_CSTRIDE;
             uint32_t* shadow_counts = wave.counts + ((size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS) * RT_CSTRIDE;
             mark();
-            hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in],
-                               ray_counts, ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, 0);
+            if (two_level)
+                hipLaunchKernelGGL(k_closest2, dim3(gridq), dim3(RT_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in], ray_counts,
+                                   (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, wave.hit2, 0);
+            else
+                hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in],
+                                   ray_counts, ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, 0);
             mark();
             mark();
             hipLaunchKernelGGL(k_classify, dim3(s->shade_blocks), dim3(RT_BLOCK), 0, st, s->view, wave, pp, b);
             for (int key : s->keys) launch_shade(s, st, wave, key, pp, b, b == o->max_depth - 1 ? 1 : 0);
             mark();
             mark();
-            if (K > 0)
+            if (K > 0 && two_level)
+                hipLaunchKernelGGL(k_shadow2, dim3(blocks_for((int64_t)K * pp.capq)), dim3(RT_BLOCK), 0, st, s->view, wave.s_o, wave.s_d,
+                                   shadow_counts, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis, 0);
+            else if (K > 0)
                 hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
                                    shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);
             mark();

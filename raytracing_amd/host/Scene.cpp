@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 
 namespace rt {
 
@@ -147,12 +148,75 @@ Rectangle::Rectangle(vec3 normal, float u_length, float v_length) { // Object.h:
     v = v_length / 2;
 }
 
+Bounds Rectangle::object_bounds() const { // Object.h:81-92
+    Bounds b(vec3(-u, 0, -v), vec3(u, 0, v));
+    const float cols[16] = {T.x, T.y, T.z, 0, N.x, N.y, N.z, 0, B.x, B.y, B.z, 0, 0, 0, 0, 1};
+    mat4 rotation = mat4::from_columns(cols);
+    return transform_bounds(b, Transform(rotation));
+}
+
+static void put3(float* d, const vec3& v) {
+    d[0] = v.x;
+    d[1] = v.y;
+    d[2] = v.z;
+}
+void Sphere::describe(rt_instance* o) const {
+    o->geometry = RT_GEO_SPHERE;
+    o->p[0] = radius;
+}
+void Rectangle::describe(rt_instance* o) const {
+    o->geometry = RT_GEO_RECTANGLE;
+    put3(o->p, N);
+    put3(o->p + 3, T);
+    put3(o->p + 6, B);
+    o->p[9] = u;
+    o->p[10] = v;
+}
+void Disk::describe(rt_instance* o) const {
+    o->geometry = RT_GEO_DISK;
+    put3(o->p, normal);
+    o->p[3] = outer_radius;
+    o->p[4] = inner_radius;
+}
+void Box::describe(rt_instance* o) const {
+    o->geometry = RT_GEO_BOX;
+    put3(o->p, bmin);
+    put3(o->p + 3, bmax);
+}
+void Cylinder::describe(rt_instance* o) const {
+    o->geometry = RT_GEO_CYLINDER;
+    o->p[0] = radius;
+    o->p[1] = ymin;
+    o->p[2] = ymax;
+}
+TriangleMesh::TriangleMesh(const Mesh* mesh_) : mesh(mesh_) { // Object.cpp:11-29
+    std::vector<Bounds> b;
+    b.reserve(mesh->triangles.size());
+    for (const MeshTriangle& t : mesh->triangles)
+        b.push_back(tri_bounds(mesh->verts[t.indicies[0]].position, mesh->verts[t.indicies[1]].position, mesh->verts[t.indicies[2]].position));
+    bvh = BVH::build(b, 1, BVH_SAH);
+    mesh_bounds = bvh.nodes[0].aabb;
+}
+void TriangleMesh::describe(rt_instance* o) const { o->geometry = RT_GEO_MESH; } // blas_root: Scene::flatten_two_level
+
 // ------------------------------------------------------------------ Scene
 Scene::~Scene() {
     if (gpu_scene) rt_scene_destroy(gpu_scene);
-    for (Material* m : materials) delete m;
+    // instances may share a geometry (one TriangleMesh placed many times) and their materials are also in `materials`
+    std::set<const void*> freed;
+    auto once = [&](auto* p) {
+        if (p && freed.insert(p).second) delete p;
+    };
+    for (Material* m : materials) once(m);
     for (Image* i : images) delete i;
-    for (Instance& l : lights) l.free_data();
+    for (Instance& l : lights) {
+        once(l.geometry);
+        once(l.material);
+    }
+    for (Instance& i : instances) {
+        once(i.geometry);
+        once(i.material);
+    }
     delete environment;
 }
 
@@ -205,17 +269,167 @@ void Scene::add_instance(const Mesh& mesh, const mat4& model_to_world, int mater
     }
 }
 
-void Scene::build_acceleration(int max_per_leaf, PartitionStrategy strat) { sceneMergedMesh.build(max_per_leaf, strat); }
+void Scene::build_acceleration(int max_per_leaf, PartitionStrategy strat) {
+    if (!instances.empty()) { // Scene::build_top_level_bvh, Scene.cpp:6-15
+        std::vector<Bounds> bounds;
+        for (size_t i = 0; i < instances.size(); i++) bounds.push_back(instances[i].get_world_bounds());
+        tlas = BVH::build(bounds, 1, BVH_SAH);
+        return;
+    }
+    sceneMergedMesh.build(max_per_leaf, strat);
+}
 
-static void put3(float* d, const vec3& v) {
-    d[0] = v.x;
-    d[1] = v.y;
-    d[2] = v.z;
+// Child-pair records of one BVH.  Numbering: the first top_pairs branch nodes in breadth-first order, then the rest in
+// pre-order (a subtree stays close in memory); layout only — visit order and arithmetic are those of the node graph.
+// leaf_ref(node) encodes a leaf; records are appended to `out`, refs are absolute indices into it.  Returns the root's ref.
+template <class LeafRef, class LeafVisit>
+static int32_t append_pairs(const BVH& bvh, int top_pairs, std::vector<rt_bvh_pair>& out, LeafRef leaf_ref, LeafVisit leaf_visit) {
+    const int first = (int)out.size();
+    std::vector<int> pair_of(bvh.nodes.size(), -1);
+    int next = first;
+    std::vector<int> level{0};
+    for (size_t head = 0; head < level.size() && next - first < top_pairs; head++) {
+        const BVHNode& nd = bvh.nodes[level[head]];
+        if (nd.count != BVH_BRANCH) continue;
+        pair_of[level[head]] = next++;
+        level.push_back(nd.left_node);
+        level.push_back(nd.left_node + 1);
+    }
+    std::vector<int> stack{0};
+    while (!stack.empty()) {
+        int n = stack.back();
+        stack.pop_back();
+        const BVHNode& nd = bvh.nodes[n];
+        if (nd.count != BVH_BRANCH) {
+            leaf_visit(nd);
+            continue;
+        }
+        if (pair_of[n] < 0) pair_of[n] = next++;
+        stack.push_back(nd.left_node + 1);
+        stack.push_back(nd.left_node);
+    }
+    out.resize(next);
+    auto ref_of = [&](int n) -> int32_t {
+        const BVHNode& nd = bvh.nodes[n];
+        return nd.count == BVH_BRANCH ? pair_of[n] : leaf_ref(nd);
+    };
+    for (size_t n = 0; n < bvh.nodes.size(); n++) {
+        if (pair_of[n] < 0) continue;
+        const BVHNode& L = bvh.nodes[bvh.nodes[n].left_node];
+        const BVHNode& R = bvh.nodes[bvh.nodes[n].left_node + 1];
+        rt_bvh_pair& p = out[pair_of[n]];
+        put3(p.lmin, L.aabb.bmin);
+        put3(p.lmax, L.aabb.bmax);
+        put3(p.rmin, R.aabb.bmin);
+        put3(p.rmax, R.aabb.bmax);
+        p.lref = ref_of(bvh.nodes[n].left_node);
+        p.rref = ref_of(bvh.nodes[n].left_node + 1);
+        p.reserved[0] = p.reserved[1] = 0;
+    }
+    return ref_of(0);
+}
+
+// Triangles of `mesh` in the leaf order of `bvh`, appended to f.tris / f.normals (rt_tri.tri_id = index within the mesh).
+static void append_triangles(const Mesh& mesh, const BVH& bvh, const std::vector<int32_t>* tri_light, FlatScene& f) {
+    const size_t base = f.tris.size(), n_tris = mesh.triangles.size();
+    f.tris.resize(base + n_tris);
+    f.normals.resize(base + n_tris);
+    for (size_t k = 0; k < n_tris; k++) {
+        const int t = bvh.indicies[k];
+        const MeshTriangle& T = mesh.triangles[t];
+        const Vertex &a = mesh.verts[T.indicies[0]], &b = mesh.verts[T.indicies[1]], &c = mesh.verts[T.indicies[2]];
+        rt_tri& o = f.tris[base + k];
+        put3(o.v0, a.position);
+        put3(o.e1, b.position - a.position); // Object.h:247-248
+        put3(o.e2, c.position - a.position);
+        o.tri_id = (uint32_t)t;
+        o.material = (int32_t)T.materialIndex;
+        o.light = tri_light ? (*tri_light)[t] : -1;
+        rt_tri_normals& nn = f.normals[base + k];
+        std::memset(&nn, 0, sizeof(nn));
+        put3(nn.n0, a.normal);
+        put3(nn.n1, b.normal);
+        put3(nn.n2, c.normal);
+    }
+}
+
+static void flatten_environment(const HDRImage* environment, FlatScene& f) {
+    // EnviormentLight::build_cdf, main.cpp:97-120 (sequential fp32 prefix sum; cdf[0] is left un-normalised as written)
+    if (environment && environment->width > 0) {
+        const int w = environment->width, h = environment->height;
+        f.env_cdf.resize((size_t)w * h);
+        auto lum = [](const vec3& c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; };
+        f.env_cdf[0] = lum(environment->get(0, 0));
+        for (int i = 1; i < w * h; i++) f.env_cdf[i] = f.env_cdf[i - 1] + lum(environment->get(i % w, i / w));
+        f.env_total = f.env_cdf[(size_t)w * h - 1];
+        for (int i = 1; i < w * h; i++) f.env_cdf[i] = f.env_cdf[i] / f.env_total;
+    }
+}
+
+static rt_light rect_light_record(const Instance& inst, int32_t material) {
+    const Rectangle* rect = static_cast<const Rectangle*>(inst.get_geometry());
+    rt_light L{};
+    L.kind = RT_LIGHT_RECT;
+    L.material = material;
+    L.area = inst.get_area(); // ignores transform scaling, Object.h:404-407
+    put3(L.n, rect->N);
+    put3(L.t, rect->T);
+    put3(L.b, rect->B);
+    L.hu = rect->u;
+    L.hv = rect->v;
+    std::memcpy(L.m, inst.get_transform().matrix().m, sizeof(L.m));
+    std::memcpy(L.inv_m, inst.get_transform().inverse_matrix().m, sizeof(L.inv_m));
+    return L;
+}
+
+// Two-level scene: every distinct TriangleMesh's BVH + triangles (model space), the TLAS, the instance table.
+void Scene::flatten_two_level() {
+    FlatScene& f = flat_scene;
+    auto material_index = [&](Material* m) -> int32_t { // a material the scene does not hold yet joins Scene::materials
+        for (size_t i = 0; i < materials.size(); i++)
+            if (materials[i] == m) return (int32_t)i;
+        materials.push_back(m);
+        return (int32_t)materials.size() - 1;
+    };
+    for (Instance& inst : instances) material_index(inst.material);
+    for (Instance& l : lights) material_index(l.material);
+    std::map<const Geometry*, int32_t> blas_root;
+    constexpr int kTopPairs = 256;
+    for (const Instance& inst : instances) {
+        const TriangleMesh* tm = dynamic_cast<const TriangleMesh*>(inst.get_geometry());
+        if (!tm || blas_root.count(tm)) continue;
+        const int32_t tri_base = (int32_t)f.tris.size();
+        append_triangles(*tm->mesh, tm->bvh, nullptr, f);
+        blas_root[tm] = append_pairs(
+            tm->bvh, kTopPairs, f.pairs, [&](const BVHNode& nd) { return ~(tri_base + nd.left_node); },
+            [&](const BVHNode& nd) { f.tris[tri_base + nd.left_node + nd.count - 1].tri_id |= RT_TRI_LEAF_END; });
+    }
+    for (const Material* m : materials) f.materials.push_back(m->flatten());
+    for (size_t i = 0; i < instances.size(); i++) {
+        const Instance& inst = instances[i];
+        rt_instance r{};
+        inst.get_geometry()->describe(&r);
+        r.material = material_index(inst.material);
+        r.blas_root = r.geometry == RT_GEO_MESH ? blas_root[inst.get_geometry()] : 0;
+        r.area = inst.get_area();
+        std::memcpy(r.m, inst.get_transform().matrix().m, sizeof(r.m));
+        std::memcpy(r.inv_m, inst.get_transform().inverse_matrix().m, sizeof(r.inv_m));
+        f.instances.push_back(r);
+    }
+    for (const Instance& l : lights) f.lights.push_back(rect_light_record(l, material_index(l.material)));
+    // TLAS: BVH::build(bounds, 1, ...) leaves one instance per leaf (Scene.cpp:13, 33-43)
+    f.tlas_root_ref = append_pairs(
+        tlas, kTopPairs, f.tlas_pairs, [&](const BVHNode& nd) { return ~tlas.indicies[nd.left_node]; }, [](const BVHNode&) {});
+    flatten_environment(environment, f);
 }
 
 void Scene::flatten() {
     FlatScene& f = flat_scene;
     f = FlatScene();
+    if (!instances.empty()) {
+        if (!tlas.nodes.empty()) flatten_two_level();
+        return;
+    }
     const Mesh& mesh = sceneMergedMesh;
     const BVH& bvh = mesh.accelStructure;
     const size_t n_tris = mesh.triangles.size();
@@ -225,18 +439,7 @@ void Scene::flatten() {
     // light per emissive material that still owns triangles.
     f.tri_light.assign(n_tris, -1);
     for (size_t i = 0; i < lights.size(); i++) {
-        const Rectangle* rect = static_cast<const Rectangle*>(lights[i].get_geometry());
-        rt_light L{};
-        L.kind = RT_LIGHT_RECT;
-        L.material = (int32_t)mesh.triangles[light_first_tri[i]].materialIndex;
-        L.area = lights[i].get_area(); // ignores transform scaling, Object.h:404-407
-        put3(L.n, rect->N);
-        put3(L.t, rect->T);
-        put3(L.b, rect->B);
-        L.hu = rect->u;
-        L.hv = rect->v;
-        std::memcpy(L.m, lights[i].get_transform().matrix().m, sizeof(L.m));
-        std::memcpy(L.inv_m, lights[i].get_transform().inverse_matrix().m, sizeof(L.inv_m));
+        const rt_light L = rect_light_record(lights[i], (int32_t)mesh.triangles[light_first_tri[i]].materialIndex);
         f.lights.push_back(L);
         f.tri_light[light_first_tri[i]] = (int32_t)i;
         f.tri_light[light_first_tri[i] + 1] = (int32_t)i;
@@ -282,90 +485,17 @@ void Scene::flatten() {
         f.lights.push_back(L);
     }
 
-    // ---- triangles in leaf order
-    f.tris.resize(n_tris);
-    f.normals.resize(n_tris);
-    for (size_t k = 0; k < n_tris; k++) {
-        const int t = bvh.indicies[k];
-        const MeshTriangle& T = mesh.triangles[t];
-        const Vertex &a = mesh.verts[T.indicies[0]], &b = mesh.verts[T.indicies[1]], &c = mesh.verts[T.indicies[2]];
-        rt_tri& o = f.tris[k];
-        put3(o.v0, a.position);
-        put3(o.e1, b.position - a.position); // Object.h:247-248
-        put3(o.e2, c.position - a.position);
-        o.tri_id = (uint32_t)t;
-        o.material = (int32_t)T.materialIndex;
-        o.light = f.tri_light[t];
-        rt_tri_normals& nn = f.normals[k];
-        std::memset(&nn, 0, sizeof(nn));
-        put3(nn.n0, a.normal);
-        put3(nn.n1, b.normal);
-        put3(nn.n2, c.normal);
-    }
-
-    // ---- child-pair records.  Numbering: the first kTopPairs branch nodes in breadth-first order (the top levels,
-    // which the traversal kernels keep in LDS), then the rest in pre-order (a subtree stays close in memory).
-    // Numbering is layout only: visit order and arithmetic are those of the reference's node graph.
+    // ---- triangles in leaf order, child-pair records (the top levels first: the traversal kernels keep them in LDS)
+    append_triangles(mesh, bvh, &f.tri_light, f);
     constexpr int kTopPairs = 256;
-    std::vector<int> pair_of(bvh.nodes.size(), -1);
-    {
-        int next = 0;
-        std::vector<int> level{0};
-        for (size_t head = 0; head < level.size() && next < kTopPairs; head++) {
-            const BVHNode& nd = bvh.nodes[level[head]];
-            if (nd.count != BVH_BRANCH) continue;
-            pair_of[level[head]] = next++;
-            level.push_back(nd.left_node);
-            level.push_back(nd.left_node + 1);
-        }
-        std::vector<int> stack{0};
-        while (!stack.empty()) {
-            int n = stack.back();
-            stack.pop_back();
-            const BVHNode& nd = bvh.nodes[n];
-            if (nd.count != BVH_BRANCH) {
-                f.tris[nd.left_node + nd.count - 1].tri_id |= RT_TRI_LEAF_END;
-                continue;
-            }
-            if (pair_of[n] < 0) pair_of[n] = next++;
-            stack.push_back(nd.left_node + 1);
-            stack.push_back(nd.left_node);
-        }
-        f.pairs.resize(next);
-    }
-    auto ref_of = [&](int n) -> int32_t {
-        const BVHNode& nd = bvh.nodes[n];
-        return nd.count == BVH_BRANCH ? pair_of[n] : ~nd.left_node;
-    };
-    f.root_ref = ref_of(0);
-    for (size_t n = 0; n < bvh.nodes.size(); n++) {
-        if (pair_of[n] < 0) continue;
-        const BVHNode& L = bvh.nodes[bvh.nodes[n].left_node];
-        const BVHNode& R = bvh.nodes[bvh.nodes[n].left_node + 1];
-        rt_bvh_pair& p = f.pairs[pair_of[n]];
-        put3(p.lmin, L.aabb.bmin);
-        put3(p.lmax, L.aabb.bmax);
-        put3(p.rmin, R.aabb.bmin);
-        put3(p.rmax, R.aabb.bmax);
-        p.lref = ref_of(bvh.nodes[n].left_node);
-        p.rref = ref_of(bvh.nodes[n].left_node + 1);
-        p.reserved[0] = p.reserved[1] = 0;
-    }
+    f.root_ref = append_pairs(
+        bvh, kTopPairs, f.pairs, [](const BVHNode& nd) { return ~nd.left_node; },
+        [&](const BVHNode& nd) { f.tris[nd.left_node + nd.count - 1].tri_id |= RT_TRI_LEAF_END; });
 
     // ---- materials
     for (const Material* m : materials) f.materials.push_back(m->flatten());
 
-    // ---- environment CDF: EnviormentLight::build_cdf, main.cpp:97-120
-    // (sequential fp32 prefix sum; cdf[0] is left un-normalised as written)
-    if (environment && environment->width > 0) {
-        const int w = environment->width, h = environment->height;
-        f.env_cdf.resize((size_t)w * h);
-        auto lum = [](const vec3& c) { return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z; };
-        f.env_cdf[0] = lum(environment->get(0, 0));
-        for (int i = 1; i < w * h; i++) f.env_cdf[i] = f.env_cdf[i - 1] + lum(environment->get(i % w, i / w));
-        f.env_total = f.env_cdf[(size_t)w * h - 1];
-        for (int i = 1; i < w * h; i++) f.env_cdf[i] = f.env_cdf[i] / f.env_total;
-    }
+    flatten_environment(environment, f);
 }
 
 bool Scene::upload(int dev) {
@@ -400,7 +530,13 @@ bool Scene::upload(int dev) {
         d.env_offset = environment_offset;
     }
     device = dev;
-    if (rt_scene_create(&d, dev, &gpu_scene) != RT_OK) {
+    rt_tlas_desc tl{};
+    tl.root_ref = f.tlas_root_ref;
+    tl.n_pairs = (int64_t)f.tlas_pairs.size();
+    tl.pairs = f.tlas_pairs.data();
+    tl.n_instances = (int32_t)f.instances.size();
+    tl.instances = f.instances.data();
+    if ((f.instances.empty() ? rt_scene_create(&d, dev, &gpu_scene) : rt_scene_create_instanced(&d, &tl, dev, &gpu_scene)) != RT_OK) {
         std::printf("Scene upload failed: %s\n", rt_last_error());
         gpu_scene = nullptr;
         return false;
@@ -423,6 +559,54 @@ bool Scene::closest_hit(Ray r, Intersection* res) const { // Scene.cpp:17-77 + O
     put3(ray.o, r.pos);
     put3(ray.d, r.dir);
     rt_hit hit;
+    if (!instances.empty()) { // Scene.cpp:17-77 over Instance::intersect (Object.h:380-394)
+        int32_t index = -1;
+        if (rt_trace_closest_indexed(gpu_scene, &ray, 1, &hit, &index) != RT_OK || index < 0) return false;
+        const Instance& inst = instances[index];
+        const Transform& tf = inst.get_transform();
+        const Ray mr(tf.to_model_point(r.pos), tf.to_model_vector(r.dir));
+        res->t = hit.t;
+        res->index = index;
+        res->material = inst.get_material();
+        res->u = hit.u;
+        res->v = hit.v;
+        res->w0 = -r.dir;
+        vec3 n; // the geometry's model-space normal, re-derived from the hit the GPU found
+        bool forward_face = false;
+        const Geometry* g = inst.get_geometry();
+        const vec3 pm = mr.at(hit.t);
+        if (const TriangleMesh* tm = dynamic_cast<const TriangleMesh*>(g)) {
+            const MeshTriangle& T = tm->mesh->triangles[hit.tri];
+            n = normalize((1 - hit.u - hit.v) * tm->mesh->verts[T.indicies[0]].normal + hit.u * tm->mesh->verts[T.indicies[1]].normal +
+                          hit.v * tm->mesh->verts[T.indicies[2]].normal);
+        } else if (const Sphere* sp = dynamic_cast<const Sphere*>(g)) {
+            n = pm / sp->radius;
+        } else if (const Rectangle* rc = dynamic_cast<const Rectangle*>(g)) {
+            n = rc->N;
+        } else if (const Disk* dk = dynamic_cast<const Disk*>(g)) {
+            n = dk->normal;
+        } else if (const Cylinder* cy = dynamic_cast<const Cylinder*>(g)) {
+            n = vec3(pm.x, 0, pm.z) / cy->radius;
+            forward_face = true; // set_forward_face, Def.h:35-39
+        } else if (const Box* bx = dynamic_cast<const Box*>(g)) {
+            int axis = 0; // the face the hit point lies on
+            float best = INFINITY;
+            for (int a = 0; a < 3; a++)
+                for (float side : {bx->bmin[a], bx->bmax[a]})
+                    if (std::fabs(pm[a] - side) < best) {
+                        best = std::fabs(pm[a] - side);
+                        axis = a;
+                    }
+            n = vec3(0);
+            n[axis] = mr.dir[axis] > 0 ? -1.f : 1.f;
+        }
+        const bool front = dot(mr.dir, n) < 0;
+        res->front_face = forward_face ? true : front;
+        n = front ? n : -n;
+        res->point = tf.to_world_point(pm);
+        res->normal = normalize(tf.to_world_normal(n));
+        return true;
+    }
     if (rt_trace_closest(gpu_scene, &ray, 1, &hit) != RT_OK || hit.tri < 0) return false;
     const MeshTriangle& T = sceneMergedMesh.triangles[hit.tri];
     res->t = hit.t;

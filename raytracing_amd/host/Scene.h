@@ -70,18 +70,65 @@ using HDRImage = Image;
 HDRImage* make_uniform_environment(int width, int height, vec3 radiance);
 HDRImage* load_hdr(const std::string& filename); // Image.cpp:6-30: Radiance RGBE -> RGB_32f, nullptr + message on failure
 
-class Geometry { // Object.h:9-24
+// Geometry (Object.h:9-24) and its subclasses.  intersect() runs on the GPU (rt_device.h: prim_intersect,
+// walk_two_level); the host classes hold the parameters, the object bounds the TLAS is built from, and describe
+// themselves as an rt_instance.
+class Geometry {
 public:
     virtual ~Geometry() {}
+    virtual Bounds object_bounds() const { return Bounds(); }
     virtual float area() const { return 0.f; }
+    virtual void describe(rt_instance* out) const = 0; // geometry tag + parameters
+};
+class Sphere : public Geometry { // Object.h:26-60
+public:
+    explicit Sphere(float radius_) : radius(radius_) {}
+    Bounds object_bounds() const override { return Bounds(vec3(-radius), vec3(radius)); }
+    void describe(rt_instance* out) const override;
+    float radius;
 };
 class Rectangle : public Geometry { // Object.h:61-135
 public:
     Rectangle(vec3 normal, vec3 tangent, float u_length, float v_length);
     Rectangle(vec3 normal, float u_length, float v_length);
+    Bounds object_bounds() const override; // Object.h:81-92
     float area() const override { return (2 * u) * (2 * v); }
+    void describe(rt_instance* out) const override;
     vec3 N, T, B;
     float u, v; // half side lengths
+};
+// The reference leaves Disk, Box and Cylinder at Geometry's empty default bounds (a TLAS over them is meaningless: the
+// empty box becomes NaN under transform_bounds).  Defined here: the box that encloses the primitive.
+class Disk : public Geometry { // Object.h:137-168
+public:
+    Disk(vec3 normal_, float outer_radius_, float inner_radius_ = -1.f) : normal(normal_), outer_radius(outer_radius_), inner_radius(inner_radius_) {}
+    Bounds object_bounds() const override { return Bounds(vec3(-outer_radius), vec3(outer_radius)); }
+    void describe(rt_instance* out) const override;
+    vec3 normal;
+    float outer_radius, inner_radius;
+};
+class Box : public Geometry { // Object.h:170-209
+public:
+    explicit Box(vec3 box_size) : bmin(box_size / -2.f), bmax(box_size / 2) {}
+    Bounds object_bounds() const override { return Bounds(bmin, bmax); }
+    void describe(rt_instance* out) const override;
+    vec3 bmin, bmax;
+};
+class Cylinder : public Geometry { // Object.h:211-243
+public:
+    Cylinder(float radius_, float height) : radius(radius_), ymin(height / -2.f), ymax(height / 2.f) {}
+    Bounds object_bounds() const override { return Bounds(vec3(-radius, ymin, -radius), vec3(radius, ymax, radius)); }
+    void describe(rt_instance* out) const override;
+    float radius, ymin, ymax;
+};
+class TriangleMesh : public Geometry { // Object.h:266-362, Object.cpp:11-29: borrows the mesh, owns its BVH
+public:
+    explicit TriangleMesh(const Mesh* mesh);
+    Bounds object_bounds() const override { return mesh_bounds; }
+    void describe(rt_instance* out) const override;
+    const Mesh* mesh;
+    BVH bvh;
+    Bounds mesh_bounds;
 };
 class Instance { // Object.h:364-423
 public:
@@ -92,11 +139,13 @@ public:
         delete material;
     }
     float get_area() const { return geometry->area(); }
+    Bounds get_world_bounds() const { return transform_bounds(geometry->object_bounds(), transform); } // Object.h:412-416
     const Material* get_material() const { return material; }
     const Geometry* get_geometry() const { return geometry; }
     const Transform& get_transform() const { return transform; }
 
 private:
+    friend class Scene; // ~Scene frees every geometry and material exactly once
     Geometry* geometry = nullptr;
     Material* material = nullptr;
     Transform transform;
@@ -123,6 +172,11 @@ struct FlatScene {
     std::vector<int32_t> emissive_orig;   // emissive[i].slot's original triangle index
     std::vector<float> env_cdf;
     float env_total = 0;
+    // legacy two-level scenes (Scene::instances not empty): pairs/tris/normals above hold every TriangleMesh's own BVH
+    // in model space, one after the other; these hold the TLAS
+    int32_t tlas_root_ref = -1;
+    std::vector<rt_bvh_pair> tlas_pairs;
+    std::vector<rt_instance> instances;
 };
 
 class Scene { // Scene.h:103-153
@@ -168,6 +222,13 @@ public:
     std::vector<Image*> images;
     std::vector<Instance> lights;
     vec3 background_color = vec3(0);
+    // The legacy design (Scene.h:137-138, commented out at HEAD; Scene.cpp:6-77 still uses them): when `instances` is
+    // not empty the scene is two-level — build_top_level_bvh builds `tlas` over the instances' world bounds
+    // (Scene.cpp:6-15), every TriangleMesh keeps its own BVH, and rays are moved into model space per instance on the
+    // GPU.  sceneMergedMesh is then unused; an Instance's material must be one of `materials` (the scene frees it).
+    // A light is an Instance(Rectangle, EmissiveMaterial) pushed into BOTH lists, as main.cpp:801-813 does.
+    std::vector<Instance> instances;
+    BVH tlas;
 
     HDRImage* environment = nullptr;
     float environment_offset = 0.f; // degrees / 360 (main.cpp:94)
@@ -179,6 +240,7 @@ private:
     FlatScene flat_scene;
     rt_scene* gpu_scene = nullptr;
     std::vector<int> light_first_tri; // per rect light: first of its two triangles
+    void flatten_two_level();
 };
 
 struct Options { // main.cpp:836-850

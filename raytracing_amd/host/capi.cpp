@@ -9,6 +9,16 @@ using namespace rt;
 
 struct rth_scene {
     Scene scene;
+    // two-level scenes: the meshes TriangleMesh geometries borrow, and those geometries (owned by the scene's instances
+    // once placed; a geometry never placed is freed here)
+    std::vector<Mesh*> meshes;
+    std::vector<TriangleMesh*> mesh_geometry;
+    std::vector<bool> mesh_placed;
+    ~rth_scene() {
+        for (size_t i = 0; i < mesh_geometry.size(); i++)
+            if (!mesh_placed[i]) delete mesh_geometry[i];
+    }
+    // (the Mesh objects outlive the Scene's destructor body: freed by free_meshes() after the scene)
 };
 
 extern "C" {
@@ -28,7 +38,81 @@ int32_t rth_bvh_build(const float* bounds6, int32_t n, int32_t max_per_node, int
 }
 
 rth_scene* rth_scene_new(void) { return new rth_scene; }
-void rth_scene_free(rth_scene* s) { delete s; }
+void rth_scene_free(rth_scene* s) {
+    std::vector<Mesh*> meshes = s->meshes;
+    delete s;
+    for (Mesh* m : meshes) delete m;
+}
+
+// ---- legacy two-level scenes: Scene::instances (Object.h:364-423) ------------------------------------------------
+// TriangleMesh(import_mesh(...)) of the scene scripts (main.cpp:456,647): builds the mesh's own BVH once; returns a
+// handle to place it with rth_scene_add_mesh_instance any number of times.
+int32_t rth_scene_new_triangle_mesh(rth_scene* s, const void* verts, int64_t n_verts, const void* tris, int64_t n_tris) {
+    Mesh* m = new Mesh;
+    const Vertex* v = (const Vertex*)verts;
+    const MeshTriangle* t = (const MeshTriangle*)tris;
+    m->verts.assign(v, v + n_verts);
+    m->triangles.assign(t, t + n_tris);
+    s->meshes.push_back(m);
+    s->mesh_geometry.push_back(new TriangleMesh(m));
+    s->mesh_placed.push_back(false);
+    return (int32_t)s->mesh_geometry.size() - 1;
+}
+// instances.push_back(Instance(mesh geometry, materials[material], transform)); returns the instance index
+int32_t rth_scene_add_mesh_instance(rth_scene* s, int32_t mesh, int32_t material, const float* transform16) {
+    if (mesh < 0 || (size_t)mesh >= s->mesh_geometry.size() || material < 0 || (size_t)material >= s->scene.materials.size()) return -1;
+    s->scene.instances.push_back(Instance(s->mesh_geometry[mesh], s->scene.materials[material], mat4::from_columns(transform16)));
+    s->mesh_placed[mesh] = true;
+    return (int32_t)s->scene.instances.size() - 1;
+}
+// instances.push_back(Instance(new <Geometry>(params), materials[material], transform)).  params by kind (RT_GEO_*):
+// SPHERE radius | RECTANGLE normal[3], u_length, v_length | DISK normal[3], outer_radius, inner_radius | BOX size[3] |
+// CYLINDER radius, height.  is_light: a second Instance of the same rectangle goes into Scene::lights (main.cpp:801-813).
+int32_t rth_scene_add_primitive_instance(rth_scene* s, int32_t kind, const float* p, int32_t material, const float* transform16, int32_t is_light) {
+    if (material < 0 || (size_t)material >= s->scene.materials.size()) return -1;
+    auto make = [&]() -> Geometry* {
+        switch (kind) {
+        case RT_GEO_SPHERE: return new Sphere(p[0]);
+        case RT_GEO_RECTANGLE: return new Rectangle(vec3(p[0], p[1], p[2]), p[3], p[4]);
+        case RT_GEO_DISK: return new Disk(vec3(p[0], p[1], p[2]), p[3], p[4]);
+        case RT_GEO_BOX: return new Box(vec3(p[0], p[1], p[2]));
+        case RT_GEO_CYLINDER: return new Cylinder(p[0], p[1]);
+        default: return nullptr;
+        }
+    };
+    Geometry* g = make();
+    if (!g) return -1;
+    if (is_light && kind != RT_GEO_RECTANGLE) {
+        delete g;
+        return -1;
+    }
+    const mat4 m = mat4::from_columns(transform16);
+    s->scene.instances.push_back(Instance(g, s->scene.materials[material], m));
+    if (is_light) s->scene.lights.push_back(Instance(make(), s->scene.materials[material], m));
+    return (int32_t)s->scene.instances.size() - 1;
+}
+// which: 0 verts, 1 triangles, 2 BVH nodes, 3 BVH indices of mesh handle `mesh`
+const void* rth_scene_mesh_array(rth_scene* s, int32_t mesh, int32_t which, int64_t* count) {
+    *count = 0;
+    if (mesh < 0 || (size_t)mesh >= s->mesh_geometry.size()) return nullptr;
+    const Mesh* m = s->meshes[mesh];
+    const BVH& b = s->mesh_geometry[mesh]->bvh;
+    switch (which) {
+    case 0: *count = (int64_t)m->verts.size(); return m->verts.data();
+    case 1: *count = (int64_t)m->triangles.size(); return m->triangles.data();
+    case 2: *count = (int64_t)b.nodes.size(); return b.nodes.data();
+    case 3: *count = (int64_t)b.indicies.size(); return b.indicies.data();
+    default: return nullptr;
+    }
+}
+// Instance::get_world_bounds (Object.h:412-416) of instance i -> out6 = (bmin, bmax)
+int32_t rth_scene_instance_bounds(rth_scene* s, int32_t i, float* out6) {
+    if (i < 0 || (size_t)i >= s->scene.instances.size()) return 0;
+    const Bounds b = s->scene.instances[i].get_world_bounds();
+    out6[0] = b.bmin.x; out6[1] = b.bmin.y; out6[2] = b.bmin.z;
+    out6[3] = b.bmax.x; out6[4] = b.bmax.y; out6[5] = b.bmax.z;
+    return 1;
+}
 
 // material_mode: GltfMaterialMode; emissive_scale multiplies emissiveFactor.
 int32_t rth_scene_load_gltf(rth_scene* s, const char* path, int32_t material_mode, float emissive_scale) {
@@ -139,7 +223,8 @@ rt_scene* rth_scene_gpu(rth_scene* s) { return s->scene.gpu(); }
 
 enum {
     RTH_VERTS = 0, RTH_TRIS, RTH_NODES, RTH_INDICES, RTH_MATERIALS, RTH_LIGHTS, RTH_EMISSIVE, RTH_TRI_LIGHT,
-    RTH_ENV_RGB, RTH_ENV_CDF, RTH_FLAT_PAIRS, RTH_FLAT_TRIS, RTH_FLAT_NORMALS, RTH_EMISSIVE_ORIG
+    RTH_ENV_RGB, RTH_ENV_CDF, RTH_FLAT_PAIRS, RTH_FLAT_TRIS, RTH_FLAT_NORMALS, RTH_EMISSIVE_ORIG,
+    RTH_TLAS_NODES, RTH_TLAS_INDICES, RTH_TLAS_PAIRS, RTH_INSTANCES
 };
 
 // Read-only views of the host arrays; *count = number of elements.
@@ -165,6 +250,10 @@ const void* rth_scene_array(rth_scene* s, int32_t which, int64_t* count) {
     case RTH_FLAT_TRIS: *count = (int64_t)f.tris.size(); return f.tris.data();
     case RTH_FLAT_NORMALS: *count = (int64_t)f.normals.size(); return f.normals.data();
     case RTH_EMISSIVE_ORIG: *count = (int64_t)f.emissive_orig.size(); return f.emissive_orig.data();
+    case RTH_TLAS_NODES: *count = (int64_t)sc.tlas.nodes.size(); return sc.tlas.nodes.data();
+    case RTH_TLAS_INDICES: *count = (int64_t)sc.tlas.indicies.size(); return sc.tlas.indicies.data();
+    case RTH_TLAS_PAIRS: *count = (int64_t)f.tlas_pairs.size(); return f.tlas_pairs.data();
+    case RTH_INSTANCES: *count = (int64_t)f.instances.size(); return f.instances.data();
     default: *count = 0; return nullptr;
     }
 }
@@ -227,12 +316,13 @@ int32_t rth_render_image(rth_scene* s, const float* view16, float fov, int32_t w
 // Scene::closest_hit / Scene::any_hit for one ray (host API smoke).
 int32_t rth_scene_closest_hit(rth_scene* s, const rt_ray* ray, float* t, float* point3, float* normal3, int32_t* front_face) {
     Intersection si;
+    si.index = -1;
     Ray r(vec3(ray->o[0], ray->o[1], ray->o[2]), vec3(ray->d[0], ray->d[1], ray->d[2]));
     if (!s->scene.closest_hit(r, &si)) return 0;
     *t = si.t;
     point3[0] = si.point.x; point3[1] = si.point.y; point3[2] = si.point.z;
     normal3[0] = si.normal.x; normal3[1] = si.normal.y; normal3[2] = si.normal.z;
-    *front_face = si.front_face ? 1 : 0;
+    *front_face = (si.front_face ? 1 : 0) | (si.index << 1); // bit 0 front_face, the rest Intersection::index
     return 1;
 }
 int32_t rth_scene_any_hit(rth_scene* s, const rt_ray* ray) {

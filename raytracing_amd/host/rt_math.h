@@ -195,6 +195,10 @@ public:
         return vec3(inv_m.m[0] * n.x + inv_m.m[1] * n.y + inv_m.m[2] * n.z, inv_m.m[4] * n.x + inv_m.m[5] * n.y + inv_m.m[6] * n.z,
                     inv_m.m[8] * n.x + inv_m.m[9] * n.y + inv_m.m[10] * n.z);
     }
+    vec3 to_model_vector(const vec3& v) const { // Math.h:675-683
+        return vec3(inv_m.m[0] * v.x + inv_m.m[4] * v.y + inv_m.m[8] * v.z, inv_m.m[1] * v.x + inv_m.m[5] * v.y + inv_m.m[9] * v.z,
+                    inv_m.m[2] * v.x + inv_m.m[6] * v.y + inv_m.m[10] * v.z);
+    }
     const mat4& matrix() const { return m; }
     const mat4& inverse_matrix() const { return inv_m; }
 
@@ -222,5 +226,16 @@ struct Bounds { // Math.h:743-786
 };
 inline Bounds bounds_union(const Bounds& a, const Bounds& b) { return Bounds(vec_min(a.bmin, b.bmin), vec_max(a.bmax, b.bmax)); }
 inline Bounds bounds_union(const Bounds& a, const vec3& v) { return Bounds(vec_min(a.bmin, v), vec_max(a.bmax, v)); }
+inline Bounds transform_bounds(const Bounds& o, const Transform& t) { // Bounds::transform_bounds, Math.h:800-812: corner order as written
+    Bounds b(t.to_world_point(o.bmin));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmax.x, o.bmin.y, o.bmin.z)));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmax.x, o.bmin.y, o.bmax.z)));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmin.x, o.bmin.y, o.bmax.z)));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmin.x, o.bmax.y, o.bmin.z)));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmin.x, o.bmax.y, o.bmax.z)));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmax.x, o.bmax.y, o.bmin.z)));
+    b = bounds_union(b, t.to_world_point(vec3(o.bmax.x, o.bmax.y, o.bmax.z)));
+    return b;
+}
 
 } // namespace rt

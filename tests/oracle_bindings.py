@@ -23,7 +23,23 @@ class OrcScene(C.Structure):
                 ("tri_light", C.c_void_p), ("n_nodes", C.c_int64), ("nodes", C.c_void_p), ("indices", C.c_void_p),
                 ("n_materials", C.c_int32), ("materials", C.c_void_p), ("n_lights", C.c_int32), ("lights", C.c_void_p),
                 ("n_emissive_tris", C.c_int32), ("emissive_tris", C.c_void_p), ("env_w", C.c_int32), ("env_h", C.c_int32),
-                ("env_rgb", C.c_void_p), ("env_cdf", C.c_void_p), ("env_total", C.c_float), ("env_offset", C.c_float)]
+                ("env_rgb", C.c_void_p), ("env_cdf", C.c_void_p), ("env_total", C.c_float), ("env_offset", C.c_float),
+                ("two_level", C.c_void_p)]
+
+
+class OrcMesh(C.Structure):
+    _fields_ = [("n_verts", C.c_int64), ("verts", C.c_void_p), ("n_tris", C.c_int64), ("tris", C.c_void_p),
+                ("n_nodes", C.c_int64), ("nodes", C.c_void_p), ("indices", C.c_void_p)]
+
+
+class OrcTwoLevel(C.Structure):
+    _fields_ = [("n_instances", C.c_int32), ("instances", C.c_void_p), ("n_meshes", C.c_int32), ("meshes", C.c_void_p),
+                ("n_tlas_nodes", C.c_int64), ("tlas_nodes", C.c_void_p), ("tlas_indices", C.c_void_p)]
+
+
+INSTANCE = np.dtype([("geometry", "<i4"), ("material", "<i4"), ("mesh", "<i4"), ("reserved", "<i4"), ("area", "<f4"),
+                     ("p", "<f4", 11), ("m", "<f4", 16), ("inv_m", "<f4", 16)])
+assert INSTANCE.itemsize == 192
 
 
 class OrcCamera(C.Structure):
@@ -60,6 +76,10 @@ def lib():
         L.orc_tri_bounds.argtypes = [vp, vp, i64, vp]
         L.orc_closest_hit.argtypes = [C.POINTER(OrcScene), vp, i64, vp, vp]
         L.orc_any_hit.argtypes = [C.POINTER(OrcScene), vp, vp, i64, vp]
+        L.orc_closest_hit2.argtypes = [C.POINTER(OrcScene), vp, i64, vp, vp, vp, vp]
+        L.orc_any_hit2.argtypes = [C.POINTER(OrcScene), vp, vp, i64, vp]
+        L.orc_world_bounds.argtypes = [vp, vp, vp]
+        L.orc_object_bounds.argtypes = [vp, vp]
         L.orc_camera_init.argtypes = [vp, f32, i32, i32, C.POINTER(OrcCamera)]
         L.orc_look_at.argtypes = [vp, vp, vp, vp]
         L.orc_camera_ray.argtypes = [C.POINTER(OrcCamera), i32, i32, u32, u32, vp]
@@ -162,6 +182,100 @@ def scene_from_host(host_scene, own_bvh=False):
     env_rgb = env.reshape(info["env_h"], info["env_w"], 3) if env.size else None
     return Scene(verts, tris, nodes, indices, host_scene.array(rta.ARR_MATERIALS), lights, emissive,
                  host_scene.array(rta.ARR_TRI_LIGHT), env_rgb, info["env_offset"])
+
+
+class TwoLevelScene(Scene):
+    """Oracle scene over Scene::instances (the legacy two-level design).  meshes = list of (verts, tris, nodes, indices)."""
+
+    def __init__(self, instances, meshes, tlas_nodes, tlas_indices, materials, lights=None, env_rgb=None, env_offset=0.0):
+        empty_v = np.zeros(0, np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("uv", "<f4", 2)]))
+        empty_t = np.zeros(0, np.dtype([("idx", "<u4", 3), ("material", "<u4")]))
+        super().__init__(empty_v, empty_t, np.zeros(0, NODE), np.zeros(0, np.int32), materials, lights, None, None, env_rgb, env_offset)
+        self.instances = np.ascontiguousarray(instances, dtype=INSTANCE)
+        self.meshes = [tuple(np.ascontiguousarray(a) for a in m) for m in meshes]
+        self.mesh_structs = (OrcMesh * max(len(self.meshes), 1))()
+        for k, (v, t, nd, ix) in enumerate(self.meshes):
+            m = self.mesh_structs[k]
+            m.n_verts, m.verts, m.n_tris, m.tris = len(v), v.ctypes.data, len(t), t.ctypes.data
+            m.n_nodes, m.nodes, m.indices = len(nd), nd.ctypes.data, ix.ctypes.data
+        self.tlas_nodes = np.ascontiguousarray(tlas_nodes, dtype=NODE)
+        self.tlas_indices = np.ascontiguousarray(tlas_indices, dtype=np.int32)
+        tl = OrcTwoLevel()
+        tl.n_instances, tl.instances = len(self.instances), self.instances.ctypes.data
+        tl.n_meshes, tl.meshes = len(self.meshes), C.addressof(self.mesh_structs)
+        tl.n_tlas_nodes, tl.tlas_nodes, tl.tlas_indices = len(self.tlas_nodes), self.tlas_nodes.ctypes.data, self.tlas_indices.ctypes.data
+        self.tl = tl
+        self.c.two_level = C.addressof(self.tl)
+
+
+def object_bounds(inst):
+    out = np.zeros(6, np.float32)
+    rec = np.ascontiguousarray(inst, dtype=INSTANCE).reshape(1)
+    lib().orc_object_bounds(_ptr(rec), _ptr(out))
+    return out
+
+
+def world_bounds(obj6, m16):
+    out = np.zeros(6, np.float32)
+    lib().orc_world_bounds(_ptr(_f32(obj6)), _ptr(_f32(m16)), _ptr(out))
+    return out
+
+
+def two_level_scene_from_host(host_scene, own_bvh=False):
+    """The oracle's two-level scene from a raytracing_amd.Scene with instances that has been build()-ed.
+    own_bvh=True: the oracle builds the mesh BVHs, the instances' world bounds and the TLAS itself."""
+    import raytracing_amd as rta
+
+    flat = host_scene.array(rta.ARR_INSTANCES)
+    inst = np.zeros(len(flat), INSTANCE)
+    for name in ("geometry", "material", "area", "p", "m", "inv_m"):
+        inst[name] = flat[name]
+    meshes = []
+    for h in range(host_scene.n_triangle_meshes):
+        v, t = host_scene.mesh_array(h, 0), host_scene.mesh_array(h, 1)
+        if own_bvh:
+            nd, ix = bvh_build(tri_bounds(v, t), 1, 1)
+        else:
+            nd, ix = host_scene.mesh_array(h, 2), host_scene.mesh_array(h, 3)
+        meshes.append((v, t, nd, ix))
+    for i in range(len(inst)):
+        inst["mesh"][i] = host_scene.instance_mesh.get(i, 0)
+    if own_bvh:
+        b = np.zeros((len(inst), 6), np.float32)
+        for i in range(len(inst)):
+            if inst["geometry"][i] == 0:
+                root = meshes[inst["mesh"][i]][2][0]
+                obj = np.concatenate([root["bmin"], root["bmax"]])
+            else:
+                obj = object_bounds(inst[i])
+            b[i] = world_bounds(obj, inst["m"][i])
+        tn, ti = bvh_build(b, 1, 1)
+    else:
+        tn, ti = host_scene.array(rta.ARR_TLAS_NODES), host_scene.array(rta.ARR_TLAS_INDICES)
+    info = host_scene.info()
+    env = host_scene.array(rta.ARR_ENV_RGB)
+    env_rgb = env.reshape(info["env_h"], info["env_w"], 3) if env.size else None
+    return TwoLevelScene(inst, meshes, tn, ti, host_scene.array(rta.ARR_MATERIALS), host_scene.array(rta.ARR_LIGHTS), env_rgb,
+                         info["env_offset"])
+
+
+def closest_hit2(scene, rays):
+    """Scene::closest_hit on a two-level scene -> (hits, index, normal, front_face)."""
+    rays = np.ascontiguousarray(rays, dtype=RAY)
+    hits = np.zeros(len(rays), HIT)
+    index = np.zeros(len(rays), np.int32)
+    normal = np.zeros((len(rays), 3), np.float32)
+    front = np.zeros(len(rays), np.uint8)
+    lib().orc_closest_hit2(C.byref(scene.c), _ptr(rays), len(rays), _ptr(hits), _ptr(index), _ptr(normal), _ptr(front))
+    return hits, index, normal, front
+
+
+def any_hit2(scene, rays, tmax):
+    rays = np.ascontiguousarray(rays, dtype=RAY)
+    tmax = _f32(tmax)
+    occ = np.zeros(len(rays), np.uint8)
+    lib().orc_any_hit2(C.byref(scene.c), _ptr(rays), _ptr(tmax), len(rays), _ptr(occ))
+    return occ
 
 
 def _cam(cam):

@@ -195,3 +195,57 @@ def random_rays(n, seed, lo=(-0.2, -0.2, -0.2), hi=(1.2, 1.2, 1.2)):
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     rays["d"] = d.astype(np.float32)
     return rays
+
+
+def _trs(translate=(0, 0, 0), scale=1.0, rot_y_deg=0.0, rot_x_deg=0.0):
+    """Column-major model-to-world: translate * rot_y * rot_x * scale."""
+    cy, sy = np.cos(np.radians(rot_y_deg)), np.sin(np.radians(rot_y_deg))
+    cx, sx = np.cos(np.radians(rot_x_deg)), np.sin(np.radians(rot_x_deg))
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    m = np.eye(4)
+    m[:3, :3] = ry @ rx * np.asarray(scale, np.float64)
+    m[:3, 3] = translate
+    return m.T.reshape(-1).astype(np.float32)
+
+
+def legacy_two_level(rta, env=0.05, light=True, mesh_lat=12, mesh_lon=24, mesh_copies=3, extra_spheres=0, seed=5):
+    """A scene of the legacy design, in the shape of the reference's BallTestScene / Conference scripts
+    (main.cpp:725-833): Scene::instances of Rectangle, Sphere, Box, Cylinder, Disk and one TriangleMesh placed several
+    times with scale + rotation + translation, a Rectangle light in both `instances` and `lights`, under a TLAS."""
+    sc = rta.Scene()
+    floor = sc.add_material(rta.material(rta.MAT_DISNEY_DIFFUSE, (0.7, 0.7, 0.7), s=(0.4, 0.5)))
+    red = sc.add_material(rta.material(rta.MAT_DISNEY_UBER, (0.6, 0.05, 0.05), s=(0.0, 0.0, 0.0, 1.0, 0.1, 0.0, 0.0, 0, 0, 0, 0, 1.5)))
+    glass = sc.add_material(rta.material(rta.MAT_DISNEY_GLASS, (1, 1, 1), s=(0.05, 0.0, 1.5)))
+    metal = sc.add_material(rta.material(rta.MAT_DISNEY_METAL, (0.7, 0.7, 0.7), s=(0.2, 0.0)))
+    ggx = sc.add_material(rta.material(rta.MAT_GGX, s=(0.4, 0.0)))
+    matte = sc.add_material(rta.material(rta.MAT_MATTE, (0.2, 0.4, 0.8)))
+    emit = sc.add_material(rta.material(rta.MAT_EMISSIVE, (17, 12, 4)))
+    sc.add_primitive_instance(rta.GEO_RECTANGLE, (0, 1, 0, 3.0, 3.0), floor, _trs())
+    for k, (z, mat) in enumerate([(0.0, red), (0.25, glass), (-0.25, metal), (-0.5, floor), (0.5, ggx)]):
+        sc.add_primitive_instance(rta.GEO_SPHERE, (0.1,), mat, _trs((0.0, 0.1, z)))
+    sc.add_primitive_instance(rta.GEO_BOX, (0.2, 0.3, 0.15), matte, _trs((0.45, 0.15, 0.3), rot_y_deg=25.0))
+    sc.add_primitive_instance(rta.GEO_CYLINDER, (0.06, 0.3), ggx, _trs((0.45, 0.15, -0.3), rot_x_deg=10.0))
+    sc.add_primitive_instance(rta.GEO_DISK, (0, 1, 0, 0.2, 0.07), metal, _trs((-0.4, 0.25, 0.0)))
+    if light:
+        sc.add_primitive_instance(rta.GEO_RECTANGLE, (0, -1, 0, 0.3, 1.3), emit, _trs((0.0, 0.9, 0.0)), light=True)
+    if mesh_copies:
+        v, t = uv_sphere(rta, mesh_lat, mesh_lon)
+        v["pos"][:, 1] *= 1.6  # an ellipsoid, so rotations matter
+        mesh = sc.new_triangle_mesh(v, t)
+        rng = np.random.default_rng(seed)
+        for k in range(mesh_copies):
+            m = _trs((-0.35 + 0.1 * k, 0.2 + 0.12 * k, -0.6 + 0.55 * k), scale=0.07 + 0.02 * k, rot_y_deg=float(rng.uniform(0, 360)),
+                     rot_x_deg=float(rng.uniform(-40, 40)))
+            sc.add_mesh_instance(mesh, [matte, red, metal][k % 3], m)
+    rng = np.random.default_rng(seed + 1)
+    for _ in range(extra_spheres):
+        p = rng.uniform((-1.2, 0.05, -1.2), (1.2, 0.8, 1.2))
+        sc.add_primitive_instance(rta.GEO_SPHERE, (float(rng.uniform(0.02, 0.06)),), int(rng.integers(0, 6)), _trs(p))
+    if env:
+        sc.set_env(np.full((8, 16, 3), env, np.float32))
+    return sc
+
+
+def legacy_camera(rta, width, height):
+    return rta.camera(rta.look_at((-1.4, 0.7, 0.0), (0.0, 0.2, 0.0), (0, 1, 0)), 45.0, width, height)

@@ -1,0 +1,150 @@
+"""-m gpu: the legacy two-level design through the C-ABI — rt_scene_create_instanced,
+rt_trace_closest_indexed, rt_trace_any, rt_render — against the oracle's restatement of Scene::closest_hit
+(Scene.cpp:17-77), Instance::intersect (Object.h:380-394), the Geometry classes and Scene::trace_scene (Scene.h:113-129).
+Bar: instance index, triangle index, t, u, v and occlusion flags bit-exact; images as in test_gpu_render.py."""
+import numpy as np
+import pytest
+
+import scenes
+from test_gpu_render import _compare
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(rta, orc, cam, w, h):
+    cam_rays = orc.camera_rays(cam, w, h, 3, 16)
+    rnd = scenes.random_rays(20000, 21, lo=(-1.0, 0.0, -1.0), hi=(1.0, 0.9, 1.0))
+    return np.concatenate([cam_rays, rnd])
+
+
+def _bounce_rays(orc, rays, hits, normal, seed):
+    """Secondary rays leaving the hit points (cosine-ish directions about the reported normal)."""
+    rng = np.random.default_rng(seed)
+    ok = hits["tri"] >= 0
+    p = rays["o"][ok] + rays["d"][ok] * hits["t"][ok, None]
+    n = normal[ok]
+    d = n + rng.normal(size=n.shape) * 0.8
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.where((d * n).sum(1, keepdims=True) < 0, -d, d)
+    out = np.zeros(len(p), orc.RAY)
+    out["o"] = (p + n * 1e-3).astype(np.float32)
+    out["d"] = d.astype(np.float32)
+    return out
+
+
+def test_closest_hit_bit_exact(rta, orc, gpu):
+    sc = scenes.legacy_two_level(rta, extra_spheres=60)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc, own_bvh=True)
+    cam = scenes.legacy_camera(rta, 160, 90)
+    rays = _rays(rta, orc, cam, 160, 90)
+    ref, ridx, rn, _ = orc.closest_hit2(osc, rays)
+    rays = np.concatenate([rays, _bounce_rays(orc, rays, ref, rn, 4)])
+    ref, ridx, rn, _ = orc.closest_hit2(osc, rays)
+    hits, idx = sc.trace_closest_indexed(rays)
+    assert np.array_equal(idx, ridx)
+    for f in ("tri", "t", "u", "v"):
+        assert np.array_equal(hits[f], ref[f]), f
+    inst = sc.array(rta.ARR_INSTANCES)
+    kinds = set(inst["geometry"][idx[idx >= 0]])
+    assert kinds == {rta.GEO_MESH, rta.GEO_SPHERE, rta.GEO_RECTANGLE, rta.GEO_DISK, rta.GEO_BOX, rta.GEO_CYLINDER}
+    assert 0.3 < (idx >= 0).mean() < 0.99
+    # rt_trace_closest on the same scene: same records without the index
+    assert np.array_equal(sc.trace_closest(rays[:5000]).tobytes(), hits[:5000].tobytes())
+
+
+def test_occlusion_flags_equal_trace_scene(rta, orc, gpu):
+    sc = scenes.legacy_two_level(rta, extra_spheres=60)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc)
+    cam = scenes.legacy_camera(rta, 160, 90)
+    rays = _rays(rta, orc, cam, 160, 90)
+    ref, ridx, rn, _ = orc.closest_hit2(osc, rays)
+    rays = np.concatenate([rays, _bounce_rays(orc, rays, ref, rn, 9)])
+    ref, _, _, _ = orc.closest_hit2(osc, rays)
+    rng = np.random.default_rng(1)
+    tmax = np.where(np.isfinite(ref["t"]), ref["t"] * rng.choice([0.5, 0.999, 1.0, 1.001, 2.0], len(rays)), rng.uniform(0.1, 3.0, len(rays)))
+    tmax = tmax.astype(np.float32)
+    tmax[::17] = np.inf
+    occ = sc.trace_any(rays, tmax)
+    want = orc.any_hit2(osc, rays, tmax)
+    assert np.array_equal(occ, want), f"{(occ != want).sum()} of {len(rays)} flags differ"
+    assert 0.2 < occ.mean() < 0.9
+    # property: occluded <=> the closest hit lies within the segment (a Box rejects t == tmax, Object.h:186: left out)
+    ne = ref["t"] != tmax
+    assert np.array_equal(occ.astype(bool)[ne], (ref["t"] <= tmax)[ne])
+
+
+def test_single_instance_and_single_triangle_roots(rta, orc, gpu):
+    """A TLAS that is one leaf and a mesh BVH that is one leaf: roots are never box-tested (Scene.cpp:20-31, Object.h:276-290)."""
+    sc = rta.Scene()
+    m = sc.add_material(rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5)))
+    v = np.zeros(3, rta.VERTEX)
+    v["pos"] = [(-1, -1, 0), (1, -1, 0), (0, 1, 0)]
+    v["normal"] = (0, 0, 1)
+    t = np.zeros(1, rta.TRIANGLE)
+    t["idx"] = (0, 1, 2)
+    sc.add_mesh_instance(sc.new_triangle_mesh(v, t), m, scenes._trs((0, 0, -4), scale=2.0))
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc)
+    rays = scenes.random_rays(2000, 5, lo=(-3, -3, -1), hi=(3, 3, 1))
+    rays["d"] = (0, 0, -1)
+    ref, ridx, _, _ = orc.closest_hit2(osc, rays)
+    hits, idx = sc.trace_closest_indexed(rays)
+    assert np.array_equal(idx, ridx) and hits.tobytes() == ref.tobytes()
+    assert 0.1 < (idx == 0).mean() < 0.9
+    assert np.allclose(hits["t"][idx == 0], rays["o"][idx == 0, 2] + 4.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("env,light", [(0.05, True), (0.0, True), (0.3, False)])
+def test_render_matches_oracle(rta, orc, gpu, env, light):
+    sc = scenes.legacy_two_level(rta, env=env, light=light)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc)
+    w, h, spp, depth = 96, 64, 8, 5
+    cam = scenes.legacy_camera(rta, w, h)
+    img, st = sc.render(cam, w, h, spp=spp, max_depth=depth, seed=7)
+    ref, oc = orc.render(osc, cam, w, h, spp, depth, seed=7)
+    _compare(img, ref)
+    assert st["paths"] == oc["paths"] == w * h * spp
+    assert abs(int(st["rays_closest"]) - int(oc["rays_closest"])) <= 0.002 * oc["rays_closest"]
+    assert abs(int(st["rays_shadow"]) - int(oc["rays_shadow"])) <= 0.002 * oc["rays_shadow"] + 2
+    # several sample passes in flight and a tile: same sums as one shot
+    img2, _ = sc.render(cam, w, h, spp=spp, max_depth=depth, seed=7, spp_per_pass=2)
+    assert np.allclose(img2, img, rtol=1e-5, atol=1e-6)
+
+
+def test_host_scene_closest_hit(rta, orc, gpu):
+    """Scene::closest_hit of the C++ host mirror on a two-level scene: point, normal, front_face, index."""
+    sc = scenes.legacy_two_level(rta)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc)
+    cam = scenes.legacy_camera(rta, 24, 16)
+    rays = orc.camera_rays(cam, 24, 16, 0, 4)
+    ref, ridx, rn, rff = orc.closest_hit2(osc, rays)
+    seen = set()
+    for i in range(len(rays)):
+        got = sc.closest_hit(rays[i])
+        if ridx[i] < 0:
+            assert got is None
+            continue
+        assert got["index"] == ridx[i] and got["t"] == ref["t"][i] and got["front_face"] == bool(rff[i])
+        assert np.allclose(got["normal"], rn[i], atol=1e-5)
+        assert np.allclose(got["point"], rays["o"][i] + rays["d"][i] * ref["t"][i], atol=1e-4)
+        seen.add(int(ridx[i]))
+    assert len(seen) >= 5
+    assert sc.any_hit(rays[np.argmax(ridx >= 0)]) and not sc.any_hit(rays[np.argmax(ridx < 0)])
+
+
+def test_rejects_bad_descriptions(rta, gpu):
+    import ctypes as C
+
+    hip, _ = rta.load_libraries()
+    out = C.c_void_p()
+    assert hip.rt_scene_create_instanced(None, None, 0, C.byref(out)) != 0
+    assert "TLAS" in rta.last_error() or "null" in rta.last_error()
