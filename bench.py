@@ -80,9 +80,10 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m"], default="cornellbox",
+    ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m", "instanced5m", "instanced5m_flat"], default="cornellbox",
                     help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow "
-                         "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces")
+                         "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces; "
+                         "instanced5m = configs[4] as a TWO-LEVEL scene: one 100k-triangle mesh placed 50 times by Instance transforms")
     args = ap.parse_args()
 
     import numpy as np
@@ -129,6 +130,18 @@ def main():
         depth = 1
         visits_json = os.path.join(ROOT, "profiles", "visits_random1m_1080p_d1.json")
         label = "1M random triangles (seed 1234), one rectangle light"
+    elif args.workload == "instanced5m":  # BASELINE configs[4], kept two-level: TLAS + ONE mesh BVH + per-instance ray transforms
+        sc = scenes.legacy_instanced(rta)
+        sc.build()
+        cam = scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
+        visits_json = os.path.join(ROOT, "profiles", "visits_instanced5m_1080p_d8.json")
+        label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), rectangle light + uniform environment"
+    elif args.workload == "instanced5m_flat":  # the same surfaces flattened into one 5 M-triangle world-space mesh (Scene::add_instance)
+        sc = scenes.legacy_instanced_flat(rta)
+        sc.build()
+        cam = scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
+        visits_json = os.path.join(ROOT, "profiles", "visits_instanced5m_flat_1080p_d8.json")
+        label = "room + one 99 856-triangle mesh x 50, FLATTENED into one 5 M-triangle mesh, rectangle light + uniform environment"
     else:  # BASELINE configs[3] geometry, one GPU's share: 614 MB of pair records + 922 MB of triangles and normals, beyond every cache
         WIDTH, HEIGHT = 3840, 2160
         sc = scenes.sphere_field(rta)
@@ -207,7 +220,8 @@ def main():
             "config": {
                 "workload": f"{label} {WIDTH}x{HEIGHT}, {depth} bounces, " + ("GGX+Beckmann materials, " if args.workload == "cornellbox" else "") + f"{spp_step} spp per step, "
                             f"{K * spp_step} spp per GPU ({spp_total}-sample Hammersley set), sample-pass sharding + one reduce",
-                "triangles": int(len(sc.array(rta.ARR_TRIS))),
+                "triangles": int(len(sc.array(rta.ARR_TRIS))) if args.workload != "instanced5m" else int(len(sc.array(rta.ARR_FLAT_TRIS))),
+                "instances": int(len(sc.array(rta.ARR_INSTANCES))),
                 "rays_closest": rays_c,
                 "rays_shadow": rays_s,
                 "rays_per_sample": rays / paths,
@@ -217,7 +231,7 @@ def main():
         }
         # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
         visits = json.load(open(visits_json)) if os.path.exists(visits_json) else None
-        kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"
+        kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"  # (k_closest2 / k_shadow2 on a two-level scene)
         if visits and max(stats["ms_closest"], stats["ms_shadow"]) > 0:
             v = visits["closest" if kern == "k_closest" else "shadow"]
             n_rays = stats["rays_closest"] if kern == "k_closest" else stats["rays_shadow"]

@@ -493,6 +493,7 @@ inline bool scene_closest_hit(const orc_two_level* tl, const V3& o, const V3& d,
                 tmp.tri = 0;
                 orc_visits iv;
                 bool hit = instance_intersect(tl, tl->instances[k], o, d, 0, t, &tmp, &iv);
+                inner += 3; // visit statistics: the instance's 192-byte record = three 64-byte units
                 inner += iv.inner;
                 leaf += iv.leaf;
                 if (!hit) continue;
@@ -527,6 +528,48 @@ inline bool scene_closest_hit(const orc_two_level* tl, const V3& o, const V3& d,
     if (vis) { vis->inner = inner; vis->leaf = leaf; }
     return std::isfinite(t);
 }
+// NOT the reference: the product's occlusion walk over a two-level scene (TLAS instead of the loop over all instances,
+// boxes beyond the segment's end skipped), restated only so that tools/measure_visits.py can count the records THAT walk
+// reads (orc_count_product_occlusion_walk).  An instance test counts as 3 inner visits (its 192-byte record).
+inline bool scene_trace_any_product_walk(const orc_two_level* tl, const V3& o, const V3& d, float tmax, orc_visits* vis) {
+    const float segment_end = (tmax > 0.f && tmax < INFINITY) ? tmax * 1.0001f + 0.000001f : (tmax <= 0.f ? tmax : INFINITY);
+    int stack[64];
+    stack[0] = 0;
+    int sp = 1, inner = 0, leaf = 0;
+    bool hit = false;
+    while (sp > 0 && !hit) {
+        const orc_node* nd = &tl->tlas_nodes[stack[--sp]];
+        if (nd->count != -1) {
+            for (int i = 0; i < nd->count && !hit; i++) {
+                const orc_instance& I = tl->instances[tl->tlas_indices[nd->left_node + i]];
+                inner += 3;
+                if (I.geometry == 0) {
+                    MeshHit h;
+                    orc_visits iv;
+                    hit = mesh_traverse(&tl->meshes[I.mesh], m4_point(I.inv_m, o), to_model_vector(I.inv_m, d), 0, tmax, true, h, &iv, true);
+                    inner += iv.inner;
+                    leaf += iv.leaf;
+                } else {
+                    GeoHit tmp;
+                    hit = instance_intersect(tl, I, o, d, 0, tmax, &tmp, nullptr);
+                }
+            }
+            continue;
+        }
+        inner++;
+        float ld, rd;
+        const orc_node* L = &tl->tlas_nodes[nd->left_node];
+        const orc_node* R = &tl->tlas_nodes[nd->left_node + 1];
+        bool lh = slab(L->bmin, L->bmax, o, d, ld) && ld < segment_end;
+        bool rh = slab(R->bmin, R->bmax, o, d, rd) && rd < segment_end;
+        if (lh) stack[sp++] = nd->left_node;
+        if (rh) stack[sp++] = nd->left_node + 1;
+    }
+    vis->inner = inner;
+    vis->leaf = leaf;
+    return hit;
+}
+
 // Scene::trace_scene (Scene.h:113-129) as a boolean: the linear loop
 inline bool scene_trace_any(const orc_two_level* tl, const V3& o, const V3& d, float tmin, float tmax, orc_visits* vis) {
     bool hit = false;
@@ -1253,7 +1296,8 @@ bool occluded(Ctx& c, const V3& o, const V3& d, float tmin, float tmax) {
     c.rays_shadow++;
     MeshHit h;
     orc_visits vis;
-    bool hit = c.s->two_level ? scene_trace_any(c.s->two_level, o, d, tmin, tmax, &vis)
+    bool hit = c.s->two_level ? (g_count_product_occlusion_walk ? scene_trace_any_product_walk(c.s->two_level, o, d, tmax, &vis)
+                                                                : scene_trace_any(c.s->two_level, o, d, tmin, tmax, &vis))
                               : mesh_traverse(c.s, o, d, tmin, tmax, true, h, &vis, g_count_product_occlusion_walk);
     c.s_inner += vis.inner;
     c.s_leaf += vis.leaf;

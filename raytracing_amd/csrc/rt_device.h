@@ -114,9 +114,9 @@ struct SceneView {
     int32_t pend_full;  // ... or once one lane holds this many (<= RT_PEND_FULL_MAX)
     int32_t wave_min_rays; // a shard of n rays is worked on by at most ceil(n / wave_min_rays) waves
     int32_t fetch_chunk;   // rays a wave takes from its shard per cursor atomic (multiple of 64)
-    // legacy two-level scenes (inst != nullptr): TLAS records, instances, k_classify's sort key per instance
-    const float4* tl_pairs;
-    const rt_instance* inst;
+    // legacy two-level scenes (inst_q != nullptr): instances, k_classify's sort key per instance
+    const float4* inst_q;  // RT_INST_QUADS float4 per instance (see "two-level scenes" below); the TLAS records lead `pairs`
+    const float4* inst_p;  // 3 float4 per instance: rt_instance.p
     const uint8_t* inst_type;
     int32_t tl_root;
     int32_t n_inst;
@@ -638,25 +638,37 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
 // ------------------------------------------------------ two-level scenes
 // Scene::closest_hit over Scene::instances (Scene.cpp:17-77): the TLAS walk; at a leaf Instance::intersect
 // (Object.h:380-394) moves the ray into model space and runs the Geometry's own test — an analytic primitive
-// (Object.h:26-243) or, for a TriangleMesh, the walk of ITS BVH (Object.h:273-344).  One loop does both levels: entering
-// a mesh swaps the lane's ray for the model-space ray and remembers the stack depth; when the stack is back at that
-// depth the mesh is finished, the world ray returns and the TLAS walk carries on.  Cull values as the reference has
-// them: the TLAS compares box distances with the closest hit over all instances (Scene.cpp:50-51), a mesh walk with the
-// closest hit found IN THIS MESH so far (Object.h:281,325-326: its local t starts infinite), while triangles are
-// accepted against the shrinking tmax handed down (Object.h:312-314).  One ray per lane, not yet the persistent
-// lane-refill scheme of trace_queue.
-#define RT_TL_LDS_STACK 16 // stack entries per lane in LDS (16 KB per 256-thread workgroup); deeper ones in private memory
+// (Object.h:26-243) or, for a TriangleMesh, the walk of ITS BVH (Object.h:273-344).
+//
+// Device layout.  TLAS records and every mesh's records share ONE pair array, TLAS first: a stack entry is a byte offset
+// whatever its level, and the LDS copy of the array's head holds the whole TLAS plus the top of the first mesh.  An
+// instance is eight float4 (rt_scene_create_instanced repacks rt_instance): [0..2] rows of world-to-model (row i =
+// inv_m[i], inv_m[4+i], inv_m[8+i], inv_m[12+i]), [3] geometry, material, blas_root (bits), area, [4..6] rows of
+// model-to-world, [7] spare; its eleven geometry parameters are three more float4 in a second array, read only for
+// analytic primitives.  (Divergent loads cost per instruction: 4 x 16 bytes per instance visit instead of 30 dwords.)
+#define RT_INST_QUADS 8
 #define RT_TL_STACK_TOTAL 128 // 64 for the TLAS (Scene.cpp:19) + 64 for the mesh (Object.h:275)
+#define RT_CUR_EXIT ((int)0x80000003) // stack marker beneath a mesh instance's entries: popping it ends the mesh walk
 
-RT_DEV V3 xf_point(const float* m, const V3& p) { // mat4 * vec4(p, 1), Math.h:368-390
-    return V3(m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12] * 1.f, m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13] * 1.f,
-              m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] * 1.f);
+struct Xf { // three rows of a 3x4 transform
+    float4 r0, r1, r2;
+};
+RT_DEV Xf load_xf(const float4* q) {
+    Xf x;
+    x.r0 = q[0];
+    x.r1 = q[1];
+    x.r2 = q[2];
+    return x;
 }
-RT_DEV V3 xf_model_vector(const float* im, const V3& v) { // Transform::to_model_vector, Math.h:675-683
-    return V3(im[0] * v.x + im[4] * v.y + im[8] * v.z, im[1] * v.x + im[5] * v.y + im[9] * v.z, im[2] * v.x + im[6] * v.y + im[10] * v.z);
+RT_DEV V3 xf_point(const Xf& m, const V3& p) { // mat4 * vec4(p, 1), Math.h:368-390: same terms in the same order
+    return V3(m.r0.x * p.x + m.r0.y * p.y + m.r0.z * p.z + m.r0.w * 1.f, m.r1.x * p.x + m.r1.y * p.y + m.r1.z * p.z + m.r1.w * 1.f,
+              m.r2.x * p.x + m.r2.y * p.y + m.r2.z * p.z + m.r2.w * 1.f);
 }
-RT_DEV V3 xf_world_normal(const float* im, const V3& n) { // Transform::to_world_normal, Math.h:667-674
-    return V3(im[0] * n.x + im[1] * n.y + im[2] * n.z, im[4] * n.x + im[5] * n.y + im[6] * n.z, im[8] * n.x + im[9] * n.y + im[10] * n.z);
+RT_DEV V3 xf_model_vector(const Xf& im, const V3& v) { // Transform::to_model_vector, Math.h:675-683 (im = world-to-model)
+    return V3(im.r0.x * v.x + im.r0.y * v.y + im.r0.z * v.z, im.r1.x * v.x + im.r1.y * v.y + im.r1.z * v.z, im.r2.x * v.x + im.r2.y * v.y + im.r2.z * v.z);
+}
+RT_DEV V3 xf_world_normal(const Xf& im, const V3& n) { // Transform::to_world_normal, Math.h:667-674: transpose of world-to-model
+    return V3(im.r0.x * n.x + im.r1.x * n.y + im.r2.x * n.z, im.r0.y * n.x + im.r1.y * n.y + im.r2.y * n.z, im.r0.z * n.x + im.r1.z * n.y + im.r2.z * n.z);
 }
 
 struct Hit2 {
@@ -671,10 +683,9 @@ RT_DEV float comp(const V3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.
 
 // Geometry::intersect of the analytic primitives with the ray in model space.  (o, d, tmin, tmax) as the reference
 // passes them; on a hit t, n (oriented), front, u, v are set.  Comparisons the reference writes against double
-// constants are made in double.
-RT_DEV bool prim_intersect(const rt_instance& I, const V3& o, const V3& d, float tmin, float tmax, Hit2* h) {
-    const float* p = I.p;
-    switch (I.geometry) {
+// constants are made in double.  p = the instance's parameters (rt_instance.p).
+RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& d, float tmin, float tmax, Hit2* h) {
+    switch (geometry) {
     case RT_GEO_SPHERE: { // Object.h:34-55
         const float radius = p[0];
         const float a = dot(d, d);
@@ -778,118 +789,174 @@ RT_DEV bool prim_intersect(const rt_instance& I, const V3& o, const V3& d, float
     }
 }
 
-// ANY = false: closest hit (h filled, returns whether anything was hit).  ANY = true: is anything hit with
-// t in [0, tmax_in] (Scene::trace_scene as a boolean, Scene.h:113-129) — boxes entered beyond the segment's end plus
-// the margin of occlusion_queue are skipped at both levels, and the walk ends at the first accepted hit.
-// lds = this lane's column of the workgroup's stack (stride RT_BLOCK).
-template <bool ANY>
-RT_DEV bool walk_two_level(const SceneView& sc, lds_int* lds, const V3& o, const V3& d, float tmax_in, Hit2* h) {
-    int spill[RT_TL_STACK_TOTAL - RT_TL_LDS_STACK];
-    h->slot = -1;
-    h->inst = -1;
-    h->t = INFINITY;
-    h->u = h->v = 0.f;
-    h->n = V3(0.f);
-    h->front = true;
-    if (sc.n_inst <= 0) return false;
-    float t_best = ANY ? tmax_in : INFINITY; // closest_so_far / Scene::closest_hit's t
-    float t_local = INFINITY;                // TriangleMesh::intersect's own t
-    const float tcull = (tmax_in > 0.f && tmax_in < INFINITY) ? tmax_in * 1.0001f + 0.000001f : (tmax_in <= 0.f ? tmax_in : INFINITY);
-    bool found = false;
-    bool dummy;
-    const RaySlab world = ray_slab(pack(o, 0.f), pack(d, 0.f), &dummy);
-    RaySlab rs = world;
-    V3 co = o, cd = d;
-    int sp = 0, base = -1, cur_inst = -1; // base >= 0: inside a mesh instance, entered at this stack depth
-    int cur = sc.tl_root;
+// The two-level walk over a sharded ray queue, as persistent wave64s with lane refill (the scheme of trace_queue).
+// One loop serves both levels.  A lane holds its CURRENT ray: the world ray in the TLAS, the model-space ray inside a
+// mesh instance.  Entering a mesh pushes RT_CUR_EXIT beneath the mesh's own entries; popping it means the mesh is
+// finished: the world ray is read back from the queue and the TLAS walk carries on.  Cull values as the reference has
+// them: the TLAS compares box distances with the closest hit over all instances (Scene.cpp:50-51), a mesh walk with
+// the closest hit found IN THIS MESH so far (Object.h:281,325-326: its local t starts infinite), while triangles are
+// accepted against the shrinking tmax handed down (Object.h:312-314).  Visit order, right-first on ties, accept on
+// equal t: the reference's, per ray, whatever rays share the wave.
+// ANY = true answers Scene::trace_scene as a boolean (Scene.h:113-129) for the segment [0, origin.w]: the walk ends at
+// the first accepted hit, and boxes (of either level) entered beyond the segment's end plus the margin of
+// occlusion_queue are skipped — the reference loops over ALL instances instead (no TLAS on that path); an instance
+// whose world box the segment misses cannot be hit by it, up to the rounding of the box test.
+// sink(queue index, hit record, found) once per ray.
+template <bool ANY, class Sink>
+RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                         const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
+                         lds_int* lds, lds_cf4* top, int top_bytes, Sink sink) {
+    int spill[RT_TL_STACK_TOTAL - RT_SHORT_STACK];
+    V3 o(0.f), d(0.f); // the lane's current ray
+    RaySlab rs;
+    rs.oxy = rs.ozz = rs.ixy = rs.izz = f2{0.f, 0.f};
+    Hit2 h;
+    h.slot = h.inst = -1;
+    h.t = INFINITY;
+    h.u = h.v = 0.f;
+    h.n = V3(0.f);
+    h.front = true;
+    float t_best = INFINITY, t_local = INFINITY, tcull = INFINITY;
+    uint32_t q = 0;
+    bool exact = false, wave_exact = false;
+    int cur = RT_CUR_DONE, sp = 0;
+    int in_inst = -1; // >= 0: inside this mesh instance
+    const float4* __restrict__ pairs = sc.pairs;
+    const float4* __restrict__ tris = sc.tris;
+    auto push = [&](int v) {
+        if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = v;
+        else if (sp < RT_TL_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = v;
+        if (sp < RT_TL_STACK_TOTAL) sp++; // (deeper than the reference's own stacks: the entry is lost, never memory)
+    };
+    auto pop = [&]() {
+        if (sp == 0) return RT_CUR_FINISH;
+        sp--;
+        return sp < RT_SHORT_STACK ? (int)lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
+    };
+    QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
-        bool pop = false;
-        if (cur >= 0) { // inner node of the current level (Scene.cpp:47-68 / Object.h:322-343)
-            const f4* p = (const f4*)((const char*)(base >= 0 ? sc.pairs : sc.tl_pairs) + (uint32_t)cur);
-            const f4 q0 = p[0], q1 = p[1], q2 = p[2];
-            const unsigned long long rr = *(const unsigned long long*)(p + 3);
-            const int lref = (int)(uint32_t)rr, rref = (int)(uint32_t)(rr >> 32);
-            float ld, rd;
-            bool lh, rh;
-            slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
-            const float cull = ANY ? tcull : (base >= 0 ? t_local : t_best);
-            lh = lh && ld < cull;
-            rh = rh && rd < cull;
-            const bool left_first = ld < rd;
-            cur = (lh && (!rh || left_first)) ? lref : rref;
-            if (lh && rh) {
-                const int far = left_first ? rref : lref;
-                if (sp < RT_TL_LDS_STACK) lds[sp * RT_BLOCK] = far;
-                else if (sp < RT_TL_STACK_TOTAL) spill[sp - RT_TL_LDS_STACK] = far;
-                if (sp < RT_TL_STACK_TOTAL) sp++; // (a tree deeper than the reference's own stacks loses the entry, never memory)
-            } else if (!lh && !rh) {
-                pop = true;
-            }
-        } else if (base >= 0) { // leaf of the mesh's BVH (Object.h:292-320)
-            int slot = ~cur;
-            bool last;
-            do {
-                float4 a, b, c;
-                load_tri(sc.tris, slot, a, b, c);
-                last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
-                float tt, u, v;
-                if (tri_accept(co, cd, a, b, c, t_best, &tt, &u, &v)) {
-                    if (ANY) return true;
-                    t_best = tt;
-                    t_local = tt;
-                    found = true;
-                    h->t = tt;
-                    h->u = u;
-                    h->v = v;
-                    h->slot = slot;
-                    h->inst = cur_inst;
-                }
-                slot++;
-            } while (!last);
-            pop = true;
-        } else { // TLAS leaf: one Instance (Scene.cpp:33-44, Object.h:380-394)
-            const int k = ~cur;
-            const rt_instance& I = sc.inst[k];
-            const V3 mo = xf_point(I.inv_m, o), md = xf_model_vector(I.inv_m, d); // Transform::to_model_ray, Math.h:692-694
-            if (I.geometry == RT_GEO_MESH) {
-                base = sp;
-                cur_inst = k;
-                co = mo;
-                cd = md;
-                rs = ray_slab(pack(mo, 0.f), pack(md, 0.f), &dummy);
+        if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
+            uint32_t idx;
+            if (queue_fetch(qs, cur == RT_CUR_DONE, &idx)) {
+                const float4 o4 = q_o[idx], d4 = q_d[idx];
+                q = idx;
+                o = V3(o4);
+                d = V3(d4);
+                rs = ray_slab(o4, d4, &exact);
+                const float tmax_in = ANY ? o4.w : INFINITY;
+                t_best = tmax_in; // closest_so_far (Scene.h:117) / Scene::closest_hit's t (Scene.cpp:25)
                 t_local = INFINITY;
-                cur = I.blas_root; // (a one-leaf mesh: its root is never box-tested, Object.h:276-290)
-                continue;
+                tcull = (tmax_in > 0.f && tmax_in < INFINITY) ? tmax_in * 1.0001f + 0.000001f : (tmax_in <= 0.f ? tmax_in : INFINITY);
+                h.slot = h.inst = -1;
+                h.t = INFINITY;
+                h.u = h.v = 0.f;
+                h.n = V3(0.f);
+                h.front = true;
+                sp = 0;
+                in_inst = -1;
+                cur = sc.n_inst > 0 ? sc.tl_root : RT_CUR_FINISH;
             }
-            Hit2 g;
-            if (prim_intersect(I, mo, md, 0.f, t_best, &g)) {
-                if (ANY) return true;
-                t_best = g.t;
-                found = true;
-                h->t = g.t;
-                h->u = g.u;
-                h->v = g.v;
-                h->n = g.n;
-                h->front = g.front;
-                h->slot = -2;
-                h->inst = k;
-            }
-            pop = true;
+            wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
         }
-        if (pop) {
-            if (base >= 0 && sp == base) { // the mesh is finished: back to the world ray and the TLAS
-                base = -1;
-                co = o;
-                cd = d;
-                rs = world;
+        if (__ballot(cur != RT_CUR_DONE) == 0ull) break;
+
+#pragma unroll
+        for (int rep = 0; rep < RT_CLOSEST_STEPS; rep++) { // inner nodes of either level (Scene.cpp:47-68 / Object.h:322-343)
+            if (cur >= 0) {
+                f4 q0, q1, q2;
+                int lref, rref;
+                load_pair(pairs, top, top_bytes, cur, q0, q1, q2, lref, rref);
+                float ld, rd;
+                bool lh, rh;
+                if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
+                else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
+                const float cull = ANY ? tcull : (in_inst >= 0 ? t_local : t_best);
+                lh = lh && ld < cull;
+                rh = rh && rd < cull;
+                const bool left_first = ld < rd;
+                cur = (lh && (!rh || left_first)) ? lref : rref;
+                if (lh && rh) push(left_first ? rref : lref);
+                else if (!lh && !rh) cur = pop();
             }
-            if (sp == 0) break;
-            sp--;
-            if (sp < RT_TL_LDS_STACK) cur = lds[sp * RT_BLOCK];
-            else cur = spill[sp - RT_TL_LDS_STACK];
+        }
+
+        const unsigned long long at_leaf = __ballot(cur < 0 && cur != RT_CUR_DONE);
+        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) continue;
+        if (cur < 0 && cur != RT_CUR_DONE) {
+            if (cur == RT_CUR_EXIT) { // the mesh is finished: the world ray comes back (Object.h:384 returns)
+                const float4 o4 = q_o[q], d4 = q_d[q];
+                o = V3(o4);
+                d = V3(d4);
+                rs = ray_slab(o4, d4, &exact);
+                in_inst = -1;
+                cur = pop();
+            } else if (cur != RT_CUR_FINISH && in_inst >= 0) { // a leaf of the mesh's BVH (Object.h:292-320)
+                int slot = ~cur;
+                bool last, stop = false;
+                do {
+                    float4 a, b, c;
+                    load_tri(tris, slot, a, b, c);
+                    last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
+                    float tt, u, v;
+                    if (tri_accept(o, d, a, b, c, t_best, &tt, &u, &v)) {
+                        t_best = tt;
+                        t_local = tt;
+                        h.t = tt;
+                        h.u = u;
+                        h.v = v;
+                        h.slot = slot;
+                        h.inst = in_inst;
+                        if (ANY) stop = last = true;
+                    }
+                    slot++;
+                } while (!last);
+                cur = stop ? RT_CUR_HIT : pop();
+            } else if (cur != RT_CUR_FINISH) { // a TLAS leaf: one Instance (Scene.cpp:33-44, Object.h:380-394)
+                const int k = ~cur;
+                const float4* iq = sc.inst_q + (size_t)k * RT_INST_QUADS;
+                const Xf w2m = load_xf(iq);
+                const float4 meta = iq[3];
+                const int geometry = __float_as_int(meta.x);
+                // the lane is in the TLAS, so (o, d) is the world ray: Transform::to_model_ray, Math.h:692-694
+                const V3 mo = xf_point(w2m, o), md = xf_model_vector(w2m, d);
+                if (geometry == RT_GEO_MESH) {
+                    push(RT_CUR_EXIT);
+                    in_inst = k;
+                    o = mo;
+                    d = md;
+                    rs = ray_slab(pack(mo, 0.f), pack(md, 0.f), &exact);
+                    t_local = INFINITY;
+                    cur = __float_as_int(meta.z); // (a one-leaf mesh: its root is never box-tested, Object.h:276-290)
+                } else {
+                    const float4* pq = sc.inst_p + (size_t)k * 3;
+                    const float4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
+                    const float p[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
+                    Hit2 g;
+                    bool stop = false;
+                    if (prim_intersect(geometry, p, mo, md, 0.f, t_best, &g)) {
+                        t_best = g.t;
+                        h.t = g.t;
+                        h.u = g.u;
+                        h.v = g.v;
+                        h.n = g.n;
+                        h.front = g.front;
+                        h.slot = -2;
+                        h.inst = k;
+                        stop = ANY;
+                    }
+                    cur = stop ? RT_CUR_HIT : pop();
+                }
+            }
+            if (cur == RT_CUR_FINISH || cur == RT_CUR_HIT) {
+                sink(q, h, ANY ? cur == RT_CUR_HIT : h.inst >= 0);
+                cur = RT_CUR_DONE;
+                exact = false;
+            }
+            wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
+        } else {
+            wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull; // (lanes of this wave may have changed their ray above)
         }
     }
-    return found;
 }
 
 // ---------------------------------------------------------------- shading

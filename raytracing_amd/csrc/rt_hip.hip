@@ -157,36 +157,31 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float
                     top_bytes, [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
 
-// ---- two-level scenes (rt_scene_create_instanced): one ray per lane over the same sharded queues
+// ---- two-level scenes (rt_scene_create_instanced): the same persistent waves over the same sharded queues
 #define RT_HIT2_FRONT 0x40000000
-RT_DEV bool tl_queue_entry(const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap, uint32_t j) {
-    const uint32_t shard = j / shard_cap;
-    return shard < n_shards && j - shard * shard_cap < counts[(size_t)shard * RT_CSTRIDE];
+__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest2(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                       const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
+                                                       uint32_t shard_cap, float4* __restrict__ hit, float4* __restrict__ hit2, int want_tri_id) {
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
+    const int top_bytes = stage_tree_top<RT_TOP_PAIRS>(sc, s_top);
+    trace_queue2<false>(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+                        [&](uint32_t q, const Hit2& h, bool) {
+                            int slot = h.slot;
+                            if (want_tri_id && slot != -1) slot = slot >= 0 ? (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END) : 0;
+                            hit[q] = make_float4(__int_as_float(slot), h.t, h.u, h.v);
+                            hit2[q] = pack(h.n, __int_as_float(h.inst < 0 ? -1 : (h.inst | (h.front ? RT_HIT2_FRONT : 0))));
+                        });
 }
-__global__ __launch_bounds__(RT_BLOCK) void k_closest2(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                                                  const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
-                                                  float4* __restrict__ hit, float4* __restrict__ hit2, int want_tri_id) {
-    __shared__ int stack[RT_TL_LDS_STACK * RT_BLOCK];
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (!tl_queue_entry(counts, n_shards, shard_cap, j)) return;
-    Hit2 h;
-    walk_two_level<false>(sc, (lds_int*)stack + threadIdx.x, V3(q_o[j]), V3(q_d[j]), INFINITY, &h);
-    int slot = h.slot;
-    if (want_tri_id && slot != -1) slot = slot >= 0 ? (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END) : 0;
-    hit[j] = make_float4(__int_as_float(slot), h.t, h.u, h.v);
-    hit2[j] = pack(h.n, __int_as_float(h.inst < 0 ? -1 : (h.inst | (h.front ? RT_HIT2_FRONT : 0))));
-}
-// out[j] = on_hit when something blocks the segment (tmax = origin.w), 1 - on_hit otherwise
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow2(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
-                                                 const uint32_t* __restrict__ counts, uint32_t n_shards, uint32_t shard_cap,
-                                                 uint8_t* __restrict__ out, int on_hit) {
-    __shared__ int stack[RT_TL_LDS_STACK * RT_BLOCK];
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (!tl_queue_entry(counts, n_shards, shard_cap, j)) return;
-    const float4 o4 = s_o[j];
-    Hit2 h;
-    const bool occluded = walk_two_level<true>(sc, (lds_int*)stack + threadIdx.x, V3(o4), V3(s_d[j]), o4.w, &h);
-    out[j] = (uint8_t)(occluded ? on_hit : 1 - on_hit);
+// out[q] = on_hit when something blocks the segment (tmax = origin.w), 1 - on_hit otherwise
+__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow2(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
+                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
+                                                      uint32_t shard_cap, uint8_t* __restrict__ out, int on_hit) {
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
+    const int top_bytes = stage_tree_top<RT_TOP_PAIRS>(sc, s_top);
+    trace_queue2<true>(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+                       [&](uint32_t q, const Hit2&, bool occluded) { out[q] = (uint8_t)(occluded ? on_hit : 1 - on_hit); });
 }
 
 // wave64 compaction over the lanes that call it (under divergence: the lanes of the current branch): ONE atomic per
@@ -259,7 +254,7 @@ __device__ unsigned long long g_shade_stats[256 * 32];
 // cost of this kernel), then walks its groups again and writes the indices.
 RT_DEV int classify_key(const SceneView& sc, const Wave& w, uint32_t q) {
     const int slot = __float_as_int(w.hit[q].x);
-    if (sc.inst) return slot == -1 ? RT_KEY_MISS : (int)sc.inst_type[__float_as_int(w.hit2[q].w) & (RT_HIT2_FRONT - 1)];
+    if (sc.inst_q) return slot == -1 ? RT_KEY_MISS : (int)sc.inst_type[__float_as_int(w.hit2[q].w) & (RT_HIT2_FRONT - 1)];
     return slot < 0 ? RT_KEY_MISS : (int)sc.tri_type[slot];
 }
 __global__ __launch_bounds__(RT_BLOCK) void k_classify(SceneView sc, Wave w, PassParams pp, int bounce) {
@@ -346,8 +341,10 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
     if (TL) { // Instance::intersect, Object.h:380-394: the Geometry's answer in model space, then point and normal to world
         const float4 g4 = w.hit2[q];
         const int iw = __float_as_int(g4.w);
-        const rt_instance& I = sc.inst[iw & (RT_HIT2_FRONT - 1)];
-        const V3 mo = xf_point(I.inv_m, ro), md = xf_model_vector(I.inv_m, rd);
+        const float4* iq = sc.inst_q + (size_t)(iw & (RT_HIT2_FRONT - 1)) * RT_INST_QUADS;
+        const Xf w2m = load_xf(iq), m2w = load_xf(iq + 4);
+        const float4 meta = iq[3];
+        const V3 mo = xf_point(w2m, ro), md = xf_model_vector(w2m, rd);
         V3 nm;
         if (slot >= 0) { // TriangleMesh::intersect tail, Object.h:350-355
             const float4* nq = sc.normals + 3 * (size_t)slot;
@@ -359,10 +356,10 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             nm = V3(g4);
             si.front_face = (iw & RT_HIT2_FRONT) != 0;
         }
-        si.point = xf_point(I.m, mo + md * h4.y);
-        si.normal = normalize(xf_world_normal(I.inv_m, nm));
-        mat_id = I.material;
-        hit_area = I.area;
+        si.point = xf_point(m2w, mo + md * h4.y);
+        si.normal = normalize(xf_world_normal(w2m, nm));
+        mat_id = __float_as_int(meta.y);
+        hit_area = meta.w;
     } else {
         // TriangleMesh::intersect tail, Object.h:350-355
         // the device copy of the normals record carries the triangle's material and light index in its pad words, so
@@ -662,7 +659,7 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
     }
     if ((rc = wave_alloc(s, &w.hit, c))) return rc;
     w.hit2 = nullptr;
-    if (s->view.inst && (rc = wave_alloc(s, &w.hit2, c))) return rc;
+    if (s->view.inst_q && (rc = wave_alloc(s, &w.hit2, c))) return rc;
     if ((rc = wave_alloc(s, &w.path, 4 * c))) return rc;
     if ((rc = wave_alloc(s, &w.s_c, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_T, kc))) return rc;
@@ -688,7 +685,7 @@ static void launch_shade(rt_scene* s, hipStream_t st, const Wave& wave, int key,
     for (size_t i = 0; i < s->keys.size(); i++) order.keys[i] = s->keys[i];
 #define RT_SHADE_CASE(K)                                                                                           \
     case K:                                                                                                        \
-        if (s->view.inst) hipLaunchKernelGGL((k_shade_t<K, true>), g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce); \
+        if (s->view.inst_q) hipLaunchKernelGGL((k_shade_t<K, true>), g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce); \
         else hipLaunchKernelGGL((k_shade_t<K, false>), g, t, 0, st, s->view, wave, pp, order, bounce, last_bounce);  \
         break;
     switch (key) {
@@ -818,21 +815,25 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
     const rt_tri* tris;
     const rt_tri_normals* normals;
     // device layout of the pair records (rt_device.h): bounds regrouped for packed arithmetic, inner refs as byte offsets
-    auto upload_pairs = [&](const rt_bvh_pair* src, int64_t n, const rt_bvh_pair** dst) {
-        std::vector<rt_bvh_pair> dev((size_t)n);
-        auto ref = [](int32_t r) { return r >= 0 ? r * RT_PAIR_BYTES : r; };
+    // (two-level: the TLAS records lead the array, every mesh's records follow with their refs moved up)
+    const int64_t n_tl = tl ? tl->n_pairs : 0;
+    if (n_tl + d->n_pairs > RT_MAX_PAIRS) return bail(fail(RT_ERR_LIMIT, "rt_scene_create: more than 2^25 - 1 child-pair records"));
+    std::vector<rt_bvh_pair> dev_pairs((size_t)(n_tl + d->n_pairs));
+    auto pack_pairs = [&](const rt_bvh_pair* src, int64_t n, int64_t at, int64_t ref_offset) {
+        auto ref = [&](int32_t r) { return r >= 0 ? (int32_t)((r + ref_offset) * RT_PAIR_BYTES) : r; };
         for (int64_t i = 0; i < n; i++) {
             const rt_bvh_pair& p = src[i];
-            float* f = (float*)&dev[(size_t)i];
+            float* f = (float*)&dev_pairs[(size_t)(at + i)];
             const float q[12] = {p.lmin[0], p.lmin[1], p.lmax[0], p.lmax[1], p.rmin[0], p.rmin[1], p.rmax[0], p.rmax[1],
                                  p.lmin[2], p.rmin[2], p.lmax[2], p.rmax[2]};
             std::memcpy(f, q, sizeof(q));
             const int32_t refs[4] = {ref(p.lref), ref(p.rref), 0, 0};
             std::memcpy(f + 12, refs, sizeof(refs));
         }
-        return upload(s, dev.data(), (size_t)n, dst);
     };
-    if ((rc = upload_pairs(d->pairs, d->n_pairs, &pairs))) return bail(rc);
+    if (tl) pack_pairs(tl->pairs, n_tl, 0, 0);
+    pack_pairs(d->pairs, d->n_pairs, n_tl, n_tl);
+    if ((rc = upload(s, dev_pairs.data(), dev_pairs.size(), &pairs))) return bail(rc);
     if ((rc = upload(s, d->tris, (size_t)d->n_tris, &tris))) return bail(rc);
     if (d->n_tris > 0) {
         std::vector<rt_tri_normals> dev(d->normals, d->normals + d->n_tris);
@@ -856,21 +857,30 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
         s->view.env_offset = d->env_offset;
     }
     if (tl) {
-        // two-level scene: TLAS records (leaf ref = ~instance), instances with blas_root in the device's ref encoding,
-        // k_classify's sort key per instance
-        const rt_bvh_pair* tl_pairs;
-        if ((rc = upload_pairs(tl->pairs, tl->n_pairs, &tl_pairs))) return bail(rc);
-        std::vector<rt_instance> inst(tl->instances, tl->instances + tl->n_instances);
+        // two-level scene: instances repacked as RT_INST_QUADS float4 (rt_device.h) + their parameters, k_classify's
+        // sort key per instance
+        std::vector<float4> iq((size_t)tl->n_instances * RT_INST_QUADS), ip((size_t)tl->n_instances * 3);
         std::vector<uint8_t> inst_type((size_t)tl->n_instances);
         int64_t per_type[RT_N_KEYS] = {};
         for (int32_t i = 0; i < tl->n_instances; i++) {
-            if (inst[(size_t)i].blas_root >= 0) inst[(size_t)i].blas_root *= RT_PAIR_BYTES;
-            inst_type[(size_t)i] = (uint8_t)d->materials[inst[(size_t)i].material].type;
+            const rt_instance& I = tl->instances[i];
+            float4* q = &iq[(size_t)i * RT_INST_QUADS];
+            for (int r = 0; r < 3; r++) {
+                q[r] = make_float4(I.inv_m[r], I.inv_m[4 + r], I.inv_m[8 + r], I.inv_m[12 + r]);
+                q[4 + r] = make_float4(I.m[r], I.m[4 + r], I.m[8 + r], I.m[12 + r]);
+            }
+            const int32_t root = I.geometry != RT_GEO_MESH ? 0 : (I.blas_root >= 0 ? (int32_t)((I.blas_root + n_tl) * RT_PAIR_BYTES) : I.blas_root);
+            q[3] = make_float4(__builtin_bit_cast(float, I.geometry), __builtin_bit_cast(float, I.material), __builtin_bit_cast(float, root), I.area);
+            q[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float p[12] = {};
+            std::memcpy(p, I.p, sizeof(I.p));
+            for (int r = 0; r < 3; r++) ip[(size_t)i * 3 + r] = make_float4(p[4 * r], p[4 * r + 1], p[4 * r + 2], p[4 * r + 3]);
+            inst_type[(size_t)i] = (uint8_t)d->materials[I.material].type;
             per_type[inst_type[(size_t)i]]++;
         }
-        if ((rc = upload(s, inst.data(), inst.size(), &s->view.inst))) return bail(rc);
+        if ((rc = upload(s, iq.data(), iq.size(), &s->view.inst_q))) return bail(rc);
+        if ((rc = upload(s, ip.data(), ip.size(), &s->view.inst_p))) return bail(rc);
         if ((rc = upload(s, inst_type.data(), inst_type.size(), &s->view.inst_type))) return bail(rc);
-        s->view.tl_pairs = (const float4*)tl_pairs;
         s->view.tl_root = tl->root_ref >= 0 ? tl->root_ref * RT_PAIR_BYTES : tl->root_ref;
         s->view.n_inst = tl->n_instances;
         for (int k = 0; k < RT_KEY_MISS; k++)
@@ -909,8 +919,8 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
     if (const char* e = getenv("RT_TUNE_FETCH_CHUNK")) s->view.fetch_chunk = std::max(64, atoi(e) / 64 * 64);
     s->view.n_lights = d->n_lights;
     s->view.n_emissive = tl ? 0 : d->n_emissive_tris;
-    s->view.n_pairs = (int32_t)std::min<int64_t>(d->n_pairs, 0x7fffffff);
-    s->n_pairs = d->n_pairs;
+    s->view.n_pairs = (int32_t)std::min<int64_t>(n_tl + d->n_pairs, 0x7fffffff);
+    s->n_pairs = n_tl + d->n_pairs;
     s->n_tris = d->n_tris;
     s->n_materials = d->n_materials;
     s->n_lights = d->n_lights;
@@ -966,7 +976,7 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     }
     float4 *d_o = nullptr, *d_d = nullptr, *d_hit = nullptr, *d_hit2 = nullptr;
     uint8_t* d_occ = nullptr;
-    const bool two_level = s->view.inst != nullptr;
+    const bool two_level = s->view.inst_q != nullptr;
     uint32_t* d_count = nullptr;
     int rc = RT_OK;
     auto cleanup = [&]() {
@@ -1002,7 +1012,7 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
         std::vector<float4> h((size_t)n), h2;
         if (two_level) {
             TRY(hipMalloc((void**)&d_hit2, (size_t)n * sizeof(float4)));
-            hipLaunchKernelGGL(k_closest2, dim3(blocks_for(piece * RT_SHARDS)), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count,
+            hipLaunchKernelGGL(k_closest2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, d_hit2, 1);
             TRY(hipGetLastError());
             h2.resize((size_t)n);
@@ -1033,7 +1043,7 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     } else {
         TRY(hipMalloc((void**)&d_occ, (size_t)n));
         if (two_level)
-            hipLaunchKernelGGL(k_shadow2, dim3(blocks_for(piece * RT_SHARDS)), dim3(RT_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count,
+            hipLaunchKernelGGL(k_shadow2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ, 1);
         else
             hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
@@ -1079,7 +1089,7 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
     const int64_t capq = shard_cap * RT_SHARDS;
     if (cap > (int64_t)1 << 30) return fail(RT_ERR_LIMIT, "rt_render: more than 2^30 paths per pass; lower spp_per_pass");
     const bool has_env = s->view.env_rgb != nullptr;
-    const bool two_level = s->view.inst != nullptr;
+    const bool two_level = s->view.inst_q != nullptr;
     const int K = (has_env ? 1 : 0) + s->n_lights;
     const int n_pass = (o->spp_count + spp_pass - 1) / spp_pass;
     // Sample passes are independent until their sums are added to the frame: with two or more, pass i runs on
@@ -1172,8 +1182,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
             uint32_t* shadow_counts = wave.counts + ((size_t)64 * RT_SHARDS + (size_t)b * RT_SHARDS) * RT_CSTRIDE;
             mark();
             if (two_level)
-                hipLaunchKernelGGL(k_closest2, dim3(gridq), dim3(RT_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in], ray_counts,
-                                   (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, wave.hit2, 0);
+                hipLaunchKernelGGL(k_closest2, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in], ray_counts,
+                                   ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, wave.hit2, 0);
             else
                 hipLaunchKernelGGL(k_closest, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.q_o[in], wave.q_d[in],
                                    ray_counts, ray_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, pp.shard_cap, wave.hit, 0);
@@ -1184,8 +1194,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
             mark();
             mark();
             if (K > 0 && two_level)
-                hipLaunchKernelGGL(k_shadow2, dim3(blocks_for((int64_t)K * pp.capq)), dim3(RT_BLOCK), 0, st, s->view, wave.s_o, wave.s_d,
-                                   shadow_counts, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis, 0);
+                hipLaunchKernelGGL(k_shadow2, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
+                                   shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis, 0);
             else if (K > 0)
                 hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
                                    shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);

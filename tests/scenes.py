@@ -249,3 +249,61 @@ def legacy_two_level(rta, env=0.05, light=True, mesh_lat=12, mesh_lon=24, mesh_c
 
 def legacy_camera(rta, width, height):
     return rta.camera(rta.look_at((-1.4, 0.7, 0.0), (0.0, 0.2, 0.0), (0, 1, 0)), 45.0, width, height)
+
+
+def legacy_instanced(rta, n_lat=159, n_lon=316, copies=50, seed=99, env=0.05):
+    """BASELINE config 5 as the legacy two-level design holds it: ONE mesh (a UV sphere of 2 n_lon (n_lat - 1) triangles:
+    99 856 by default) placed `copies` times by Instance transforms — one BVH of 100k triangles in memory instead of the
+    5 M flattened ones — inside a room of five Rectangle instances, under a Rectangle light."""
+    sc = rta.Scene()
+    white = sc.add_material(rta.material(rta.MAT_DISNEY_DIFFUSE, (0.725, 0.71, 0.68), s=(0.5, 0.5)))
+    red = sc.add_material(rta.material(rta.MAT_MATTE, (0.63, 0.065, 0.05)))
+    green = sc.add_material(rta.material(rta.MAT_MATTE, (0.14, 0.45, 0.091)))
+    ggx = sc.add_material(rta.material(rta.MAT_GGX, s=(0.35, 0.0)))
+    metal = sc.add_material(rta.material(rta.MAT_DISNEY_METAL, (0.8, 0.6, 0.3), s=(0.3, 0.0)))
+    emit = sc.add_material(rta.material(rta.MAT_EMISSIVE, (17, 12, 4)))
+    R = rta.GEO_RECTANGLE
+    sc.add_primitive_instance(R, (0, 1, 0, 3.2, 3.2), white, _trs((0, 0, 0)))
+    sc.add_primitive_instance(R, (0, -1, 0, 3.2, 3.2), white, _trs((0, 3.2, 0)))
+    sc.add_primitive_instance(R, (0, 0, 1, 3.2, 3.2), white, _trs((0, 1.6, -1.6)))
+    sc.add_primitive_instance(R, (1, 0, 0, 3.2, 3.2), red, _trs((-1.6, 1.6, 0)))
+    sc.add_primitive_instance(R, (-1, 0, 0, 3.2, 3.2), green, _trs((1.6, 1.6, 0)))
+    sc.add_primitive_instance(R, (0, -1, 0, 0.8, 0.8), emit, _trs((0, 3.19, 0)), light=True)
+    v, t = uv_sphere(rta, n_lat, n_lon)
+    mesh = sc.new_triangle_mesh(v, t)
+    for k, m in enumerate(instance_transforms(copies, seed, scale=(0.12, 0.3))):
+        sc.add_mesh_instance(mesh, [ggx, metal, white][k % 3], m)
+    if env:
+        sc.set_env(np.full((8, 16, 3), env, np.float32))
+    return sc
+
+
+def legacy_instanced_camera(rta, width, height):
+    return rta.camera(rta.look_at((0.0, 1.6, 5.4), (0.0, 1.5, 0.0), (0, 1, 0)), 40.0, width, height)
+
+
+def legacy_instanced_flat(rta, n_lat=159, n_lon=316, copies=50, seed=99, env=0.05):
+    """The geometry of legacy_instanced() flattened at set-up into ONE world-space mesh (Scene::add_instance): what the
+    target design does with config 5.  Same surfaces, materials, light and camera, 5 M triangles in memory."""
+    sc = rta.Scene()
+    white = sc.add_material(rta.material(rta.MAT_DISNEY_DIFFUSE, (0.725, 0.71, 0.68), s=(0.5, 0.5)))
+    red = sc.add_material(rta.material(rta.MAT_MATTE, (0.63, 0.065, 0.05)))
+    green = sc.add_material(rta.material(rta.MAT_MATTE, (0.14, 0.45, 0.091)))
+    ggx = sc.add_material(rta.material(rta.MAT_GGX, s=(0.35, 0.0)))
+    metal = sc.add_material(rta.material(rta.MAT_DISNEY_METAL, (0.8, 0.6, 0.3), s=(0.3, 0.0)))
+    a = 1.6
+    for corners, n, mat in [
+        ([(-a, 0, a), (a, 0, a), (a, 0, -a), (-a, 0, -a)], (0, 1, 0), white),
+        ([(-a, 2 * a, -a), (a, 2 * a, -a), (a, 2 * a, a), (-a, 2 * a, a)], (0, -1, 0), white),
+        ([(-a, 0, -a), (a, 0, -a), (a, 2 * a, -a), (-a, 2 * a, -a)], (0, 0, 1), white),
+        ([(-a, 0, a), (-a, 0, -a), (-a, 2 * a, -a), (-a, 2 * a, a)], (1, 0, 0), red),
+        ([(a, 0, -a), (a, 0, a), (a, 2 * a, a), (a, 2 * a, -a)], (-1, 0, 0), green),
+    ]:
+        sc.add_mesh(*_quad(rta, corners, n, mat))
+    sc.add_rect_light((0, -1, 0), 0.8, 0.8, (17, 12, 4), _trs((0, 3.19, 0)))
+    v, t = uv_sphere(rta, n_lat, n_lon)
+    for k, m in enumerate(instance_transforms(copies, seed, scale=(0.12, 0.3))):
+        sc.add_instance(v, t, m, material=[ggx, metal, white][k % 3])
+    if env:
+        sc.set_env(np.full((8, 16, 3), env, np.float32))
+    return sc

@@ -148,3 +148,31 @@ def test_rejects_bad_descriptions(rta, gpu):
     out = C.c_void_p()
     assert hip.rt_scene_create_instanced(None, None, 0, C.byref(out)) != 0
     assert "TLAS" in rta.last_error() or "null" in rta.last_error()
+
+
+def test_config5_two_level_scale(rta, orc, gpu):
+    """BASELINE config 5 kept two-level: one 99 856-triangle mesh placed 50 times (5 M triangles if flattened; here one
+    BVH of 100k) in a room of Rectangle instances.  Closest hits and occlusion flags bit-exact, image within the bar."""
+    sc = scenes.legacy_instanced(rta)
+    sc.build()
+    sc.upload(gpu)
+    inst, tris = sc.array(rta.ARR_INSTANCES), sc.array(rta.ARR_FLAT_TRIS)
+    assert len(inst) == 56 and len(tris) == 99_856 and (inst["geometry"] == rta.GEO_MESH).sum() == 50
+    osc = orc.two_level_scene_from_host(sc)
+    w, h = 160, 90
+    cam = scenes.legacy_instanced_camera(rta, w, h)
+    rays = orc.camera_rays(cam, w, h, 1, 8)
+    ref, ridx, rn, _ = orc.closest_hit2(osc, rays)
+    rays = np.concatenate([rays, _bounce_rays(orc, rays, ref, rn, 2)])
+    ref, ridx, rn, _ = orc.closest_hit2(osc, rays)
+    hits, idx = sc.trace_closest_indexed(rays)
+    assert np.array_equal(idx, ridx) and hits.tobytes() == ref.tobytes()
+    on_mesh = inst["geometry"][idx[idx >= 0]] == rta.GEO_MESH
+    assert 0.1 < on_mesh.mean() < 0.9
+    rng = np.random.default_rng(3)
+    tmax = (np.where(np.isfinite(ref["t"]), ref["t"], 1.0) * rng.choice([0.7, 0.9999, 1.0001, 1.5], len(rays))).astype(np.float32)
+    assert np.array_equal(sc.trace_any(rays, tmax), orc.any_hit2(osc, rays, tmax))
+    img, st = sc.render(cam, w, h, spp=4, max_depth=6, seed=5)
+    ref_img, oc = orc.render(osc, cam, w, h, 4, 6, seed=5)
+    _compare(img, ref_img)
+    assert st["paths"] == oc["paths"]

@@ -33,6 +33,13 @@ elif WORKLOAD == "spheres10m":  # BASELINE config 4 geometry: 9.6 M triangles (t
     cam = scenes.random_triangles_camera(rta, W, H)
     label = "10 000 tessellated spheres (9.6 M triangles, seed 1234), rectangle light + uniform environment, depth 8"
     name = "visits_spheres10m_4k_d8.json"
+elif WORKLOAD == "instanced5m":  # BASELINE config 5 as a two-level scene (an instance test counts as 3 inner visits: its 192-byte record)
+    W, H, SPP, DEPTH = 480, 270, 2, 8
+    sc = scenes.legacy_instanced(rta)
+    sc.build()
+    cam = scenes.legacy_instanced_camera(rta, W, H)
+    label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), depth 8"
+    name = "visits_instanced5m_1080p_d8.json"
 else:  # BASELINE config 3: 1 000 000 random triangles, primary + shadow rays only (depth 1); the SAH build takes ~40 s
     W, H, SPP, DEPTH = 480, 270, 2, 1
     sc = scenes.random_triangles(rta, 1_000_000)
@@ -40,7 +47,7 @@ else:  # BASELINE config 3: 1 000 000 random triangles, primary + shadow rays on
     cam = scenes.random_triangles_camera(rta, W, H)
     label = "1 000 000 random triangles in the unit box (seed 1234), one rectangle light, depth 1"
     name = "visits_random1m_1080p_d1.json"
-osc = orc.scene_from_host(sc)
+osc = orc.two_level_scene_from_host(sc) if WORKLOAD == "instanced5m" else orc.scene_from_host(sc)
 orc.lib().orc_count_product_occlusion_walk(1)  # shadow-ray visits of the walk the kernels run (boxes beyond tmax skipped)
 _, c = orc.render(osc, cam, W, H, SPP, DEPTH, seed=1, spp_total=1024)
 orc.lib().orc_count_product_occlusion_walk(0)
