@@ -159,7 +159,13 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float
 
 // ---- two-level scenes (rt_scene_create_instanced): the same persistent waves over the same sharded queues
 #define RT_HIT2_FRONT 0x40000000
-__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest2(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+// waves per SIMD the two-level kernels are compiled for: 8 = two 1024-thread workgroups per CU (64 VGPRs; the closest walk
+// then keeps 8 dwords in scratch).  Measured on config 5 two-level, one pass at a time: 4 waves (78 / 66 VGPRs) closest
+// 181.8 ms, shadow 175.8 ms per 3 steps; 8 waves 170.2 and 129.3.
+#ifndef RT_TL_WAVES
+#define RT_TL_WAVES 8
+#endif
+__global__ __launch_bounds__(RT_TRAV_BLOCK, RT_TL_WAVES) void k_closest2(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                        const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                        uint32_t shard_cap, float4* __restrict__ hit, float4* __restrict__ hit2, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest2(SceneView sc, const 
                         });
 }
 // out[q] = on_hit when something blocks the segment (tmax = origin.w), 1 - on_hit otherwise
-__global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow2(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
+__global__ __launch_bounds__(RT_TRAV_BLOCK, RT_TL_WAVES) void k_shadow2(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
                                                       const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                       uint32_t shard_cap, uint8_t* __restrict__ out, int on_hit) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];

@@ -141,6 +141,7 @@ public:
     float get_area() const { return geometry->area(); }
     Bounds get_world_bounds() const { return transform_bounds(geometry->object_bounds(), transform); } // Object.h:412-416
     const Material* get_material() const { return material; }
+    Material* get_material_ptr() const { return material; } // to place the same material in a second Instance (a light in both lists)
     const Geometry* get_geometry() const { return geometry; }
     const Transform& get_transform() const { return transform; }
 
