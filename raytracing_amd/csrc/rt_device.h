@@ -209,16 +209,6 @@ RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_by
         q1 = p[1];
         q2 = p[2];
         const unsigned long long rr = *(const unsigned long long*)(p + 3); // 56 of the record's 64 bytes are read
-#ifdef RT_EXTRA_LOADS // experiment: redundant loads of the record's unused tail, to see what a load instruction costs
-        for (int xl = 0; xl < RT_EXTRA_LOADS; xl++) {
-#ifdef RT_EXTRA_COALESCED
-            const unsigned long long xx = *(const volatile unsigned long long*)((const char*)pairs + 8 * __lane_id());
-#else
-            const unsigned long long xx = *(const volatile unsigned long long*)((const char*)p + 56);
-#endif
-            asm volatile("" ::"v"(xx));
-        }
-#endif
         lref = (int)(uint32_t)rr;
         rref = (int)(uint32_t)(rr >> 32);
     }

@@ -555,10 +555,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp,
     if (w.vis[j]) direct = direct + V3(c0);
     for (uint32_t r = 1; r < n; r++)
         if (w.vis[j + r]) direct = direct + V3(w.s_c[j + r]);
+    // nothing arrives (every ray blocked, or lights seen from behind): radiance + 0 is radiance (it is never -0: it starts
+    // at +0 and the NaN / inf cases fail this test), so the path record — a random 64-byte sector — is left alone
+    const V3 add = V3(T4) * direct;
+    if (add.x == 0.f && add.y == 0.f && add.z == 0.f) return;
     float4* pr = w.path + 4 * (size_t)p + 1;
     const float4 rk = *pr;
     V3 rad(rk);
-    rad = rad + V3(T4) * direct;
+    rad = rad + add;
     *pr = pack(rad, rk.w);
 }
 
