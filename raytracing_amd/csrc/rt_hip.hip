@@ -48,15 +48,19 @@ static int fail(int code, const std::string& msg) {
 
 // Per-pass wavefront state.  cap = paths per pass.
 struct Wave {
-    // ray queues (double buffered), indexed by queue position
+    // ray queues (double buffered), indexed by queue position.  The path's state TRAVELS WITH ITS RAY: a queue entry is
+    // four float4 streams, gathered through `perm` (mostly ascending within a material's list) and written at the next
+    // queue position in lane order.  (One 64-byte record per path id was a random HBM sector read and written per shaded
+    // hit: a queue entry's path id is random after the first compaction.)
     float4* q_o[2];   // origin.xyz, path id (bits)
-    float4* q_d[2];   // dir.xyz, unused
+    float4* q_d[2];   // dir.xyz, random-number counter (bits)
+    float4* q_T[2];   // throughput.xyz, scatter_pdf
+    float4* q_p[2];   // prev.point.xyz (main.cpp:437), random-number key (bits)
     float4* hit;      // slot (bits), t, u, v
     float4* hit2;     // two-level scenes only: analytic primitive's oriented model-space normal, instance | front_face << 30 (bits)
-    // path state, indexed by path id: ONE 64-byte record per path (a queue entry's path id is random, so every access
-    // is its own HBM sector: three 16-byte arrays cost three sectors per read and three partial-line writes)
-    //   [0] throughput.xyz, scatter_pdf   [1] radiance.xyz, rng key (bits)   [2] prev.point.xyz, rng counter (bits)   [3] spare
-    float4* path;
+    // radiance.xyz of every path, indexed by path id: touched only when something arrives (an emitter is hit, the path
+    // leaves the scene under an environment, next-event estimation finds light)
+    float4* rad;
     // Dense shadow-ray queue; the next-event-estimation records live in it, at the rays' own positions: a lane's shadow
     // rays are consecutive entries and lanes reserve in order, so every NEE store is a coalesced 1-KiB burst.  (Records
     // indexed by the shaded queue entry were scattered 16-byte writes in material order: with their resolve pass a third
@@ -100,11 +104,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     V3 o, d;
     camera_ray(pp.cam, x, y, (uint32_t)(pp.spp_first + s_local), pp.spp_total, &o, &d);
     w.q_o[0][p] = pack(o, __int_as_float(p));
-    w.q_d[0][p] = pack(d, 0.f);
-    float4* ps = w.path + 4 * (size_t)p;
-    ps[0] = make_float4(1.f, 1.f, 1.f, 1.f);
-    ps[1] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rng_key((uint32_t)(y * pp.width + x), (uint32_t)(pp.spp_first + s_local), pp.seed)));
-    ps[2] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+    w.q_d[0][p] = pack(d, __int_as_float(0));
+    w.q_T[0][p] = make_float4(1.f, 1.f, 1.f, 1.f);
+    w.q_p[0][p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rng_key((uint32_t)(y * pp.width + x), (uint32_t)(pp.spp_first + s_local), pp.seed)));
+    w.rad[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     if ((uint32_t)p < pp.n_shards) { // the dense camera-ray queue, cut into n_shards pieces for the traversal waves
         const int64_t left = (int64_t)pp.cap - (int64_t)p * pp.shard_cap;
         w.counts[(size_t)p * RT_CSTRIDE] = (uint32_t)(left < 0 ? 0 : (left > (int64_t)pp.shard_cap ? (int64_t)pp.shard_cap : left));
@@ -318,16 +321,13 @@ template <int KEY, bool TL, class TB>
 RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const PassParams& pp, int bounce, int last_bounce, uint32_t q, uint32_t out_shard) {
     SH_T0
     const int in = bounce & 1, out = in ^ 1;
-    const float4 o4 = w.q_o[in][q], d4 = w.q_d[in][q], h4 = w.hit[q];
+    const float4 o4 = w.q_o[in][q], d4 = w.q_d[in][q], tp = w.q_T[in][q], h4 = w.hit[q];
     const int p = __float_as_int(o4.w);
     const V3 ro(o4), rd(d4);
     const int slot = __float_as_int(h4.x);
-    float4* ps = w.path + 4 * (size_t)p;
-    const float4 tp = ps[0], rk = ps[1];
     V3 T(tp);
     const float scatter_pdf = tp.w;
-    V3 rad(rk);
-    SH_MARK(0); // queue + path state loads
+    SH_MARK(0); // queue entry loads
 
     if (KEY == RT_KEY_MISS) { // main.cpp:340-359
         if (pp.has_env) {
@@ -335,8 +335,7 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             V3 bg = env_eval(sc, tb, rd, &env_pdf);
             float mw = 1.f;
             if (bounce > 0) mw = power_heuristic(scatter_pdf, env_pdf);
-            rad = rad + (T * bg) * mw;
-            ps[1] = pack(rad, rk.w);
+            w.rad[p] = pack(V3(w.rad[p]) + (T * bg) * mw, 0.f);
         }
         SH_MARK(1); // miss: environment lookup
         return;
@@ -384,10 +383,10 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
     rt_material mat = sc.materials[mat_id];
     mat.type = KEY; // compile-time constant: the material switches below fold to this kernel's one case
 
-    const float4 pv = ps[2];
+    const float4 pv = w.q_p[in][q];
     Rng rng;
-    rng.key = __float_as_uint(rk.w); // rng_key(pixel, sample, seed), stored by k_generate
-    rng.ctr = __float_as_uint(pv.w);
+    rng.key = __float_as_uint(pv.w); // rng_key(pixel, sample, seed), stored by k_generate
+    rng.ctr = __float_as_uint(d4.w);
 
     const V3 emitted = mat_emitted(mat);
     float weight = 1.f;
@@ -401,8 +400,10 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             weight = power_heuristic(scatter_pdf, lpdf);
         }
     }
-    rad = rad + (weight * emitted) * T;
-    ps[1] = pack(rad, rk.w);
+    // radiance += weight * emitted * throughput (main.cpp:401).  Adding an exact zero leaves the radiance as it is (it is
+    // never -0), so only emitters touch the path's radiance here; a NaN (0 * inf throughput) fails the test and is added.
+    const V3 add = (weight * emitted) * T;
+    if (!(add.x == 0.f && add.y == 0.f && add.z == 0.f)) w.rad[p] = pack(V3(w.rad[p]) + add, 0.f);
     SH_MARK(2); // surface, material fetch, emission
 
     Scatter scat = mat_sample(mat, si, rd, rng);
@@ -466,12 +467,12 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
     SH_MARK(5); // light NEE
 
     T = (T * scat.f) / scat.pdf; // main.cpp:434
-    ps[0] = pack(T, scat.pdf);
-    ps[2] = pack(si.point, __uint_as_float(rng.ctr));
-    if (!last_bounce) { // next-bounce ray queue, compacted over the surviving lanes
+    if (!last_bounce) { // next-bounce ray queue, compacted over the surviving lanes; the path's state goes with the ray
         const uint32_t qi = out_shard * pp.shard_cap + wave_reserve(1u, false, &w.counts[(size_t)((uint32_t)(bounce + 1) * pp.n_shards + out_shard) * RT_CSTRIDE]);
         w.q_o[out][qi] = pack(scat.origin, __int_as_float(p));
-        w.q_d[out][qi] = pack(scat.dir, 0.f);
+        w.q_d[out][qi] = pack(scat.dir, __uint_as_float(rng.ctr));
+        w.q_T[out][qi] = pack(T, scat.pdf);
+        w.q_p[out][qi] = pack(si.point, pv.w);
     }
     SH_MARK(6); // path state + next ray
 }
@@ -559,11 +560,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp,
     // at +0 and the NaN / inf cases fail this test), so the path record — a random 64-byte sector — is left alone
     const V3 add = V3(T4) * direct;
     if (add.x == 0.f && add.y == 0.f && add.z == 0.f) return;
-    float4* pr = w.path + 4 * (size_t)p + 1;
-    const float4 rk = *pr;
-    V3 rad(rk);
-    rad = rad + add;
-    *pr = pack(rad, rk.w);
+    w.rad[p] = pack(V3(w.rad[p]) + add, 0.f);
 }
 
 // pixel_total += s with the NaN guard of main.cpp:984-987, samples in index order
@@ -575,7 +572,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(Wave w, PassParams pp, 
     float* px = sum + ((size_t)y * pp.width + x) * 3;
     V3 total(px[0], px[1], px[2]);
     for (int s = 0; s < pp.spp_pass; s++) {
-        V3 v(w.path[4 * ((size_t)s * pp.npix + pix) + 1]);
+        V3 v(w.rad[(size_t)s * pp.npix + pix]);
         if (v.x != v.x) v = V3(0.f);
         total = total + v;
     }
@@ -666,11 +663,13 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
     for (int i = 0; i < 2; i++) {
         if ((rc = wave_alloc(s, &w.q_o[i], c))) return rc;
         if ((rc = wave_alloc(s, &w.q_d[i], c))) return rc;
+        if ((rc = wave_alloc(s, &w.q_T[i], c))) return rc;
+        if ((rc = wave_alloc(s, &w.q_p[i], c))) return rc;
     }
     if ((rc = wave_alloc(s, &w.hit, c))) return rc;
     w.hit2 = nullptr;
     if (s->view.inst_q && (rc = wave_alloc(s, &w.hit2, c))) return rc;
-    if ((rc = wave_alloc(s, &w.path, 4 * c))) return rc;
+    if ((rc = wave_alloc(s, &w.rad, c))) return rc;
     if ((rc = wave_alloc(s, &w.s_c, kc))) return rc;
     if ((rc = wave_alloc(s, &w.s_T, kc))) return rc;
     if ((rc = wave_alloc(s, &w.vis, kc))) return rc;
