@@ -3,7 +3,7 @@
 
 Workload: cornellbox.glb (13 170 triangles) at 1920x1080, 8 bounces, GGX + Beckmann material mapping, camera from the
 file's Camera node chain, uniform 16x8 environment.  One "step" = one rt_render call tracing SPP_STEP samples per pixel
-of a (steps x SPP_STEP x n_gpus)-sample Hammersley set; the default 64 steps x 16 spp = the configuration's 1024 spp.
+of a (steps x SPP_STEP x n_gpus)-sample Hammersley set; the default 32 steps x 32 spp = the configuration's 1024 spp (rt_render cuts a step into four 8-spp wavefront passes in flight).
 Multi-GPU: sample-pass sharding — rank r renders its own window of sample indices (no data-path collective) and ONE
 RCCL reduce of the fp32 radiance buffer to rank 0 closes the frame (inside the timed region).
 
@@ -19,12 +19,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 16  # (main() raises the raster for --workload spheres10m)
+WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 32  # (main() raises the raster for --workload spheres10m)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 VISITS_JSON = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
 # rocprofv3 --pmc passes over `bench.py --steps 1` (tools/profile_pmc.sh + tools/summarize_pmc.py), FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950; roofline.traffic = HBM bytes per launch of the dominant kernel from it
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary_v4.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary_v6.json")
 
 
 def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
@@ -75,7 +75,7 @@ def main():
     global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
