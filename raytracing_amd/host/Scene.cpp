@@ -589,14 +589,16 @@ bool Scene::closest_hit(Ray r, Intersection* res) const { // Scene.cpp:17-77 + O
             n = vec3(pm.x, 0, pm.z) / cy->radius;
             forward_face = true; // set_forward_face, Def.h:35-39
         } else if (const Box* bx = dynamic_cast<const Box*>(g)) {
-            int axis = 0; // the face the hit point lies on
-            float best = INFINITY;
-            for (int a = 0; a < 3; a++)
-                for (float side : {bx->bmin[a], bx->bmax[a]})
-                    if (std::fabs(pm[a] - side) < best) {
-                        best = std::fabs(pm[a] - side);
-                        axis = a;
-                    }
+            int axis = 0; // Box::intersect's own slab loop (Object.h:176-198): the axis that set the entry distance
+            float tmin = 0, greatest_minimum = -INFINITY;
+            for (int a = 0; a < 3; a++) {
+                float t0 = std::fmin((bx->bmin[a] - mr.pos[a]) / mr.dir[a], (bx->bmax[a] - mr.pos[a]) / mr.dir[a]);
+                tmin = std::fmax(t0, tmin);
+                if (tmin > greatest_minimum) {
+                    greatest_minimum = tmin;
+                    axis = a;
+                }
+            }
             n = vec3(0);
             n[axis] = mr.dir[axis] > 0 ? -1.f : 1.f;
         }

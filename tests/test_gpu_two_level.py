@@ -176,3 +176,16 @@ def test_config5_two_level_scale(rta, orc, gpu):
     ref_img, oc = orc.render(osc, cam, w, h, 4, 6, seed=5)
     _compare(img, ref_img)
     assert st["paths"] == oc["paths"]
+
+
+def test_cli_balltest_scene(rta, gpu, tmp_path, capfd):
+    """python -m raytracing_amd balltest: the reference's BallTestScene as a two-level scene, through Renderer::render_image."""
+    from raytracing_amd.__main__ import main
+
+    out = tmp_path / "balls.bmp"
+    assert main(["balltest", "-o", str(out), "--width", "96", "--height", "64", "--spp", "8", "--depth", "4", "--env", "0.5"]) == 0
+    data = out.read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 96 * 3 * 64
+    px = np.frombuffer(data[54:], np.uint8)
+    assert 20 < px.mean() < 250 and px.std() > 5  # something other than a flat frame
+    assert "6 instances" in capfd.readouterr().out
