@@ -110,8 +110,6 @@ struct SceneView {
     float env_total, env_offset;
     int32_t refill_min; // refill a wave's idle lanes once this many are idle
     int32_t leaf_min;   // test pending leaves once this many lanes wait at one (or no lane has an inner node)
-    int32_t pend_min;   // occlusion walk: test pending leaves once this many lanes hold one
-    int32_t pend_full;  // ... or once one lane holds this many (<= RT_PEND_FULL_MAX)
     int32_t wave_min_rays; // a shard of n rays is worked on by at most ceil(n / wave_min_rays) waves
     int32_t fetch_chunk;   // rays a wave takes from its shard per cursor atomic (multiple of 64)
     // legacy two-level scenes (inst_q != nullptr): instances, k_classify's sort key per instance
@@ -473,23 +471,14 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 }
 
 #define RT_CUR_HIT ((int)0x80000002)    // occlusion_queue: an occluder was found
-#ifndef RT_PEND_CAP
-#define RT_PEND_CAP 8 // pending-leaf entries per lane in LDS (occlusion_queue)
+#ifndef RT_OCC_STEPS
+#define RT_OCC_STEPS 2 // inner steps per round of the occlusion walk (1: 6.65, 2: 6.71, 3: 6.76, 4: 6.72 Grays/s — noise level)
 #endif
-#define RT_PEND_FULL_MAX (RT_PEND_CAP - 3) // a round of two inner steps adds at most 4 entries: it starts with <= CAP - 4
-#ifndef RT_OCC_STACK
-#define RT_OCC_STACK 8 // occlusion walk: stack entries per lane kept in LDS.  With the pending list and the tree top a
-#endif                 // 1024-thread workgroup holds 32 + 32 + 16 = 80 KB: two of them fill a CU's 160 KB
-
-// Boolean occlusion (trace_scene as used at main.cpp:250,281) over a sharded ray queue.  The answer of the reference's
-// any-hit walk does not depend on the order of its steps: its `t` stays infinite until the first accepted triangle
-// ends the walk, so a leaf is reached exactly when the box tests of all its ancestors pass, and the ray is occluded
-// exactly when some reached leaf holds a triangle that passes IntersectTriRay2 with 1e-4 < t <= tmax.  This walk
-// therefore evaluates the same tests on the same nodes but never lets a lane wait at a leaf: a child that is a leaf
-// and whose box is hit goes to a short per-lane pending list (LDS) and the lane carries on with inner nodes; the
-// pending triangles are tested together, one per lane and turn, once enough lanes hold one (pend_min), a lane holds
-// pend_full of them, or no lane has an inner node left.  Persistent waves, per-shard fetch cursors and LDS/private
-// stack as in trace_queue.  sink(queue index, tag = the ray's dir.w bits, occluded) is called once per ray.
+// Boolean occlusion (trace_scene as used at main.cpp:250,281) over a sharded ray queue: the closest walk's loop — two
+// inner steps per round for all lanes, then the lanes at a leaf test their triangles together; persistent waves,
+// per-shard fetch cursors, LDS/private stack as in trace_queue — ending a ray at the first accepted triangle, as the
+// reference's walk does (near child first, Object.h:328-337).  sink(queue index, tag = the ray's dir.w bits, occluded)
+// is called once per ray.
 //
 // ONE step outside the reference's procedure: a child box whose entry distance exceeds the segment's end by more than
 // a margin (dist >= tmax * 1.0001 + 1e-6) is not entered.  The reference enters it (its cull value `t` is infinite until a hit, Object.h:281,325-326) and then
@@ -501,20 +490,22 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
 // parity tests compare this walk with the oracle's reference-faithful walk, flag for flag (tests/test_gpu_trace.py,
 // test_golden.py, test_gpu_scale.py: 2.4 M segments, random and light-directed).  It removes 19 % of the inner visits
 // and 41 % of the triangle tests of the bench workload's shadow rays (they end 1e-3 in front of a tessellated light).
+//
+// (Until round 1's last day this was an order-free walk that parked hit leaves in a per-lane pending list in LDS and
+// tested them in batches — 80 KB of LDS per workgroup.  With everything else in place the plain loop is 4 % faster alone
+// and, at 48 KB, shares the CUs better with the other passes' kernels: 6.55 -> 6.75 Grays/s.)
 template <class Sink>
 RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
-                            const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
-                            lds_int* lds, lds_int* pend, lds_cf4* top, int top_bytes, Sink sink) {
-    int spill[RT_STACK_TOTAL - RT_OCC_STACK];
+                               const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
+                               lds_int* lds, lds_cf4* top, int top_bytes, Sink sink) {
+    int spill[RT_STACK_TOTAL - RT_SHORT_STACK];
     V3 o(0.f), d(0.f);
     RaySlab rs;
     rs.oxy = rs.ozz = rs.ixy = rs.izz = f2{0.f, 0.f};
     float tmax = 0.f, tcull = 0.f;
     uint32_t q = 0, tag = 0;
-    bool exact = false;
-    bool wave_exact = false; // wave-uniform: some lane fetched a ray that needs the select-form slab test
-    int cur = RT_CUR_DONE;
-    int sp = 0, np = 0; // stack depth; pending leaves
+    bool exact = false, wave_exact = false;
+    int cur = RT_CUR_DONE, sp = 0;
     const float4* __restrict__ pairs = sc.pairs;
     const float4* __restrict__ tris = sc.tris;
     RT_STAT_DECL
@@ -530,27 +521,16 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 d = V3(d4);
                 rs = ray_slab(o4, d4, &exact);
                 tmax = o4.w;
-                // boxes entered beyond the segment's end (plus a margin of 1e-4 relative + 1e-6, a thousand times the
-                // rounding of the slab and triangle arithmetic on well-conditioned input) are skipped; a segment that
-                // cannot hold an accepted hit (tmax <= 0) skips everything, a non-finite tmax nothing
                 tcull = (tmax > 0.f && tmax < INFINITY) ? tmax * 1.0001f + 0.000001f : (tmax <= 0.f ? tmax : INFINITY);
                 sp = 0;
-                if (sc.root_ref >= 0) {
-                    cur = sc.root_ref;
-                    np = 0;
-                } else { // the whole mesh is one leaf; the root is never box-tested (Object.h:283-290)
-                    pend[0] = sc.root_ref;
-                    np = 1;
-                    cur = RT_CUR_FINISH;
-                }
+                cur = sc.root_ref;
             }
             wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
         }
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break;
         RT_STAT(3, cur != RT_CUR_DONE);
-
 #pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
+        for (int rep = 0; rep < RT_OCC_STEPS; rep++) {
             RT_STAT(0, cur >= 0);
             RT_STAT(2, cur >= 0 && cur < top_bytes);
             if (cur >= 0) {
@@ -561,65 +541,56 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 bool lh, rh;
                 if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
                 else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
-                lh = lh && ld < tcull; // `dist < t` of Object.h:325-326 with t still infinite, and dist <= tmax
+                lh = lh && ld < tcull;
                 rh = rh && rd < tcull;
-                if (lh && lref < 0) {
-                    pend[np * RT_TRAV_BLOCK] = lref;
-                    np++;
-                }
-                if (rh && rref < 0) {
-                    pend[np * RT_TRAV_BLOCK] = rref;
-                    np++;
-                }
-                const bool li = lh && lref >= 0, ri = rh && rref >= 0;
                 const bool left_first = ld < rd;
-                cur = (li && (!ri || left_first)) ? lref : rref;
-                if (li && ri) {
+                cur = (lh && (!rh || left_first)) ? lref : rref;
+                if (lh && rh) {
                     const int far = left_first ? rref : lref;
-                    if (sp < RT_OCC_STACK) lds[sp * RT_TRAV_BLOCK] = far;
-                    else if (sp < RT_STACK_TOTAL) spill[sp - RT_OCC_STACK] = far;
+                    if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = far;
+                    else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
                     sp++;
-                } else if (!li && !ri) {
+                } else if (!lh && !rh) {
                     if (sp == 0) {
                         cur = RT_CUR_FINISH;
                     } else {
                         sp--;
-                        if (sp < RT_OCC_STACK) cur = lds[sp * RT_TRAV_BLOCK];
-                        else cur = spill[sp - RT_OCC_STACK];
+                        if (sp < RT_SHORT_STACK) cur = lds[sp * RT_TRAV_BLOCK];
+                        else cur = spill[sp - RT_SHORT_STACK];
                     }
                 }
             }
         }
-
-        const unsigned long long has_pend = __ballot(np > 0);
-        bool go = has_pend != 0ull && (__ballot(np >= sc.pend_full) != 0ull || __ballot(cur >= 0) == 0ull ||
-                                       __popcll(has_pend) >= sc.pend_min);
-        while (go) {
-            RT_STAT(1, np > 0);
-            if (np > 0) {
-                np--;
-                int slot = ~pend[np * RT_TRAV_BLOCK];
-                bool last;
+        const unsigned long long at_leaf = __ballot(cur < 0 && cur != RT_CUR_DONE);
+        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) continue;
+        if (cur < 0 && cur != RT_CUR_DONE) {
+            if (cur != RT_CUR_FINISH) {
+                int slot = ~cur;
+                bool last, stop = false;
+                RT_STAT(1, true);
                 do {
                     float4 a, b, c;
                     load_tri(tris, slot, a, b, c);
                     last = (__float_as_uint(a.w) & RT_TRI_LEAF_END) != 0u;
                     float tt, u, v;
-                    if (tri_accept(o, d, a, b, c, tmax, &tt, &u, &v)) {
-                        cur = RT_CUR_HIT;
-                        np = 0;
-                        sp = 0;
-                        last = true;
-                    }
+                    if (tri_accept(o, d, a, b, c, tmax, &tt, &u, &v)) stop = last = true;
                     slot++;
                 } while (!last);
+                if (stop) {
+                    cur = RT_CUR_HIT;
+                } else if (sp == 0) {
+                    cur = RT_CUR_FINISH;
+                } else {
+                    sp--;
+                    if (sp < RT_SHORT_STACK) cur = lds[sp * RT_TRAV_BLOCK];
+                    else cur = spill[sp - RT_SHORT_STACK];
+                }
             }
-            go = __ballot(np >= sc.pend_full) != 0ull || (__ballot(cur >= 0) == 0ull && __ballot(np > 0) != 0ull);
-        }
-        if (cur == RT_CUR_HIT || (cur == RT_CUR_FINISH && np == 0)) {
-            sink(q, tag, cur == RT_CUR_HIT);
-            cur = RT_CUR_DONE;
-            exact = false;
+            if (cur == RT_CUR_FINISH || cur == RT_CUR_HIT) {
+                sink(q, tag, cur == RT_CUR_HIT);
+                cur = RT_CUR_DONE;
+                exact = false;
+            }
         }
     }
     RT_STAT_FLUSH(8);

@@ -140,24 +140,22 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const f
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
                                                      uint32_t n_shards, uint32_t shard_cap, uint8_t* __restrict__ vis) {
-    __shared__ int stack[RT_OCC_STACK * RT_TRAV_BLOCK];
-    __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
     const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
-    occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
-                    top_bytes, [&](uint32_t q, uint32_t, bool occluded) { vis[q] = occluded ? 0 : 1; });
+    occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+                    [&](uint32_t q, uint32_t, bool occluded) { vis[q] = occluded ? 0 : 1; });
 }
 
 // Parity hook variant: rays + tmax in, occluded flag out (rt_trace_any).
 __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                                                   const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                   uint32_t shard_cap, uint8_t* __restrict__ occ) {
-    __shared__ int stack[RT_OCC_STACK * RT_TRAV_BLOCK];
-    __shared__ int pend[RT_PEND_CAP * RT_TRAV_BLOCK];
+    __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
     const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
-    occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)pend + threadIdx.x, (lds_cf4*)s_top,
-                    top_bytes, [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
+    occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+                    [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
 
 // ---- two-level scenes (rt_scene_create_instanced): the same persistent waves over the same sharded queues
@@ -916,14 +914,10 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
     s->view.root_ref = d->root_ref >= 0 ? d->root_ref * RT_PAIR_BYTES : d->root_ref;
     s->view.refill_min = 16;
     s->view.leaf_min = 16;
-    s->view.pend_min = 48;
-    s->view.pend_full = std::min(5, RT_PEND_FULL_MAX);
     s->view.wave_min_rays = 0;
     s->view.fetch_chunk = 128;
     if (const char* e = getenv("RT_TUNE_REFILL_MIN")) s->view.refill_min = std::max(1, atoi(e));
     if (const char* e = getenv("RT_TUNE_LEAF_MIN")) s->view.leaf_min = std::max(1, atoi(e));
-    if (const char* e = getenv("RT_TUNE_PEND_MIN")) s->view.pend_min = std::max(1, atoi(e));
-    if (const char* e = getenv("RT_TUNE_PEND_FULL")) s->view.pend_full = std::min(RT_PEND_FULL_MAX, std::max(1, atoi(e)));
     if (const char* e = getenv("RT_TUNE_WAVE_MIN")) s->view.wave_min_rays = std::max(0, atoi(e));
     if (const char* e = getenv("RT_TUNE_FETCH_CHUNK")) s->view.fetch_chunk = std::max(64, atoi(e) / 64 * 64);
     s->view.n_lights = d->n_lights;
