@@ -124,3 +124,21 @@ def test_two_level_render_runs_on_oracle(rta, orc):
     img, c = orc.render(osc, cam, 32, 24, 4, 4, seed=2)
     assert np.isfinite(img).all() and img.mean() > 0.05
     assert c["paths"] == 32 * 24 * 4 and c["rays_shadow"] > 0.5 * c["rays_closest"]  # env + one light per shaded hit
+
+
+def _build_example(tmp_path):
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "legacy_scene")
+    pkg = os.path.join(root, "raytracing_amd")
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(root, "examples", "legacy_scene.cpp"), "-I" + os.path.join(pkg, "host"), "-L" + pkg,
+                    "-lrt_host", "-lrt_hip", "-Wl,-rpath," + pkg, "-o", exe], check=True)
+    return exe
+
+
+def test_cpp_scene_script_compiles_against_the_host_mirror(tmp_path):
+    """a scene script in the reference's own shape (Instance(new Sphere(...), material, offset), ...)
+    compiles and links against librt_host.so / librt_hip.so."""
+    assert _build_example(tmp_path)

@@ -99,7 +99,7 @@ def test_single_instance_and_single_triangle_roots(rta, orc, gpu):
     assert np.allclose(hits["t"][idx == 0], rays["o"][idx == 0, 2] + 4.0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("env,light", [(0.05, True), (0.0, True), (0.3, False)])
+@pytest.mark.parametrize("env,light", [(0.05, True), (0.0, True), (0.3, False), (0.0, False)])
 def test_render_matches_oracle(rta, orc, gpu, env, light):
     sc = scenes.legacy_two_level(rta, env=env, light=light)
     sc.build()
@@ -189,3 +189,20 @@ def test_cli_balltest_scene(rta, gpu, tmp_path, capfd):
     px = np.frombuffer(data[54:], np.uint8)
     assert 20 < px.mean() < 250 and px.std() > 5  # something other than a flat frame
     assert "6 instances" in capfd.readouterr().out
+
+
+def test_cpp_scene_script_renders(gpu, tmp_path):
+    """The C++ example (examples/legacy_scene.cpp): Scene::instances + build_top_level_bvh + Renderer::render_image."""
+    import subprocess
+
+    from test_cpu_two_level import _build_example
+
+    exe = _build_example(tmp_path)
+    out = tmp_path / "legacy.bmp"
+    r = subprocess.run([exe, str(out), "96", "64", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "centre ray: instance" in r.stdout and f"{96 * 64 * 8} paths" in r.stdout
+    data = out.read_bytes()
+    assert data[:2] == b"BM" and len(data) == 54 + 96 * 3 * 64
+    px = np.frombuffer(data[54:], np.uint8)
+    assert px.mean() > 10 and px.std() > 5
