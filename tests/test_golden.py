@@ -94,3 +94,45 @@ def test_gpu_reproduces_golden_image(rta, gpu, vec, host_cornell):
     want = vec["image_rays"]
     assert stats["paths"] == want[2]
     assert abs(stats["rays_closest"] + stats["rays_shadow"] - want[0] - want[1]) <= 1e-3 * (want[0] + want[1])
+
+
+# ---- the legacy two-level design (tests/golden/two_level_vectors.npz)
+@pytest.fixture(scope="module")
+def vec2():
+    return np.load(os.path.join(GOLD, "two_level_vectors.npz"))
+
+
+@pytest.fixture(scope="module")
+def host_two_level(rta):
+    sc = scenes.legacy_two_level(rta, extra_spheres=20)
+    sc.build()
+    return sc
+
+
+def test_oracle_reproduces_golden_two_level(rta, orc, vec2, host_two_level):
+    osc = orc.two_level_scene_from_host(host_two_level, own_bvh=True)
+    for which in ("primary", "secondary"):
+        hits, index, normal, front = orc.closest_hit2(osc, vec2[which])
+        assert np.array_equal(index, vec2[which + "_index"])
+        assert hits.tobytes() == vec2[which + "_hits"].tobytes()
+        assert np.array_equal(normal, vec2[which + "_normal"]) and np.array_equal(front, vec2[which + "_front"])
+    assert np.array_equal(orc.any_hit2(osc, vec2["secondary"], vec2["secondary_tmax"]), vec2["secondary_occluded"])
+    img, stats = orc.render(osc, scenes.legacy_camera(rta, 48, 32), 48, 32, 8, 5, seed=6)
+    assert np.array_equal(img, vec2["image_48x32_8spp_d5_seed6"])
+    assert [stats["rays_closest"], stats["rays_shadow"], stats["paths"]] == vec2["image_rays"].tolist()
+    assert len(set(vec2["primary_index"].tolist())) >= 8 and 0.05 < vec2["secondary_occluded"].mean() < 0.95
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_two_level(rta, gpu, vec2, host_two_level):
+    host_two_level.upload(gpu)
+    for which in ("primary", "secondary"):
+        hits, index = host_two_level.trace_closest_indexed(vec2[which])
+        assert np.array_equal(index, vec2[which + "_index"])
+        assert hits.tobytes() == vec2[which + "_hits"].tobytes()
+    assert np.array_equal(host_two_level.trace_any(vec2["secondary"], vec2["secondary_tmax"]), vec2["secondary_occluded"])
+    img, stats = host_two_level.render(scenes.legacy_camera(rta, 48, 32), 48, 32, spp=8, max_depth=5, seed=6)
+    ref = vec2["image_48x32_8spp_d5_seed6"]
+    rel = float(np.sqrt(np.mean((img - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
+    assert rel < 1e-3, rel
+    assert stats["paths"] == vec2["image_rays"][2]

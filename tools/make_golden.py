@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes tests/golden/cornell_vectors.npz and tests/golden/material_vectors.npz from the CPU oracle (oracle/, test
+"""Writes tests/golden/cornell_vectors.npz, material_vectors.npz and two_level_vectors.npz from the CPU oracle (oracle/, test
 infrastructure).  The reference ships no tests, fixtures or golden vectors and cannot be built in this image (DESIGN.md
 §2), so these vectors pin the ORACLE AS IT IS TODAY: a later change to the oracle, the host BVH builder, the flattener
 or the HIP kernels that alters any hit index, t, u, v, occlusion flag, BSDF value or image shows up as a diff against
@@ -88,8 +88,30 @@ def materials():
     np.savez_compressed(os.path.join(OUT, "material_vectors.npz"), **out)
 
 
+def two_level():
+    """The legacy two-level design: scenes.legacy_two_level (six geometry kinds, one mesh placed three times, a light)."""
+    sc = scenes.legacy_two_level(rta, extra_spheres=20)
+    sc.build()
+    osc = orc.two_level_scene_from_host(sc)
+    cam = scenes.legacy_camera(rta, 64, 64)
+    prim = orc.camera_rays(cam, 64, 64, 1, 4)
+    h1, i1, n1, f1 = orc.closest_hit2(osc, prim)
+    sec = secondary(prim, h1, 41)[:4096]
+    h2, i2, n2, f2 = orc.closest_hit2(osc, sec)
+    tmax = (np.random.default_rng(43).random(len(sec)) * 1.5).astype(np.float32)
+    tmax[::5] = np.inf
+    occ = orc.any_hit2(osc, sec, tmax)
+    img, stats = orc.render(osc, scenes.legacy_camera(rta, 48, 32), 48, 32, 8, 5, seed=6)
+    np.savez_compressed(os.path.join(OUT, "two_level_vectors.npz"), primary=prim, primary_hits=h1, primary_index=i1, primary_normal=n1,
+                        primary_front=f1, secondary=sec, secondary_hits=h2, secondary_index=i2, secondary_normal=n2, secondary_front=f2,
+                        secondary_tmax=tmax, secondary_occluded=occ, image_48x32_8spp_d5_seed6=img,
+                        image_rays=np.array([stats["rays_closest"], stats["rays_shadow"], stats["paths"]], np.int64))
+
+
 if __name__ == "__main__":
-    cornell()
-    materials()
-    for f in ("cornell_vectors.npz", "material_vectors.npz"):
+    if "--only-two-level" not in sys.argv:
+        cornell()
+        materials()
+    two_level()
+    for f in ("cornell_vectors.npz", "material_vectors.npz", "two_level_vectors.npz"):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
