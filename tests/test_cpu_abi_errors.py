@@ -1,0 +1,159 @@
+"""CPU (-m "not gpu"): argument and description checks of the C-ABI (include/rt_hip.h).  Every reference a kernel would
+follow is validated on the host before anything touches a GPU, so a bad description is an error code with a message,
+never a GPU memory fault; and without a GPU a good description fails loudly (RT_ERR_NO_DEVICE): there is no CPU path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import scenes
+
+RT_OK, RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_LIMIT = 0, 1, 2, 3, 4
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("root_ref", C.c_int32), ("n_pairs", C.c_int64), ("pairs", C.c_void_p), ("n_tris", C.c_int64), ("tris", C.c_void_p),
+                ("normals", C.c_void_p), ("n_materials", C.c_int32), ("materials", C.c_void_p), ("n_lights", C.c_int32),
+                ("lights", C.c_void_p), ("n_emissive_tris", C.c_int32), ("emissive_tris", C.c_void_p), ("env_w", C.c_int32),
+                ("env_h", C.c_int32), ("env_rgb", C.c_void_p), ("env_cdf", C.c_void_p), ("env_total", C.c_float), ("env_offset", C.c_float)]
+
+
+class TlasDesc(C.Structure):
+    _fields_ = [("root_ref", C.c_int32), ("n_pairs", C.c_int64), ("pairs", C.c_void_p), ("n_instances", C.c_int32), ("instances", C.c_void_p)]
+
+
+def _flat(rta):
+    sc = scenes.quad_room(rta)
+    sc.build()
+    a = {k: sc.array(getattr(rta, "ARR_" + k)) for k in ("FLAT_PAIRS", "FLAT_TRIS", "FLAT_NORMALS", "MATERIALS", "LIGHTS", "EMISSIVE")}
+    d = SceneDesc()
+    d.root_ref = sc.info()["root_ref"]
+    d.n_pairs, d.pairs = len(a["FLAT_PAIRS"]), a["FLAT_PAIRS"].ctypes.data
+    d.n_tris, d.tris, d.normals = len(a["FLAT_TRIS"]), a["FLAT_TRIS"].ctypes.data, a["FLAT_NORMALS"].ctypes.data
+    d.n_materials, d.materials = len(a["MATERIALS"]), a["MATERIALS"].ctypes.data
+    d.n_lights, d.lights = len(a["LIGHTS"]), a["LIGHTS"].ctypes.data
+    d.n_emissive_tris, d.emissive_tris = len(a["EMISSIVE"]), (a["EMISSIVE"].ctypes.data if len(a["EMISSIVE"]) else None)
+    return sc, a, d
+
+
+def _two_level(rta):
+    sc = scenes.legacy_two_level(rta, env=0)
+    sc.build()
+    a = {k: sc.array(getattr(rta, "ARR_" + k)) for k in ("FLAT_PAIRS", "FLAT_TRIS", "FLAT_NORMALS", "MATERIALS", "LIGHTS", "TLAS_PAIRS", "INSTANCES")}
+    d = SceneDesc()
+    d.n_pairs, d.pairs = len(a["FLAT_PAIRS"]), a["FLAT_PAIRS"].ctypes.data
+    d.n_tris, d.tris, d.normals = len(a["FLAT_TRIS"]), a["FLAT_TRIS"].ctypes.data, a["FLAT_NORMALS"].ctypes.data
+    d.n_materials, d.materials = len(a["MATERIALS"]), a["MATERIALS"].ctypes.data
+    d.n_lights, d.lights = len(a["LIGHTS"]), a["LIGHTS"].ctypes.data
+    t = TlasDesc()
+    t.root_ref = 0
+    t.n_pairs, t.pairs = len(a["TLAS_PAIRS"]), a["TLAS_PAIRS"].ctypes.data
+    t.n_instances, t.instances = len(a["INSTANCES"]), a["INSTANCES"].ctypes.data
+    return sc, a, d, t
+
+
+def _create(rta, d, tl=None):
+    hip, _ = rta.load_libraries()
+    out = C.c_void_p()
+    rc = hip.rt_scene_create(C.byref(d), 0, C.byref(out)) if tl is None else hip.rt_scene_create_instanced(C.byref(d), C.byref(tl), 0, C.byref(out))
+    msg = rta.last_error()
+    if rc == RT_OK:
+        hip.rt_scene_destroy.argtypes = [C.c_void_p]
+        hip.rt_scene_destroy(out)
+    return rc, msg
+
+
+def _good(rta, rc):
+    """A valid description: created where a GPU is present, RT_ERR_NO_DEVICE (loudly) where none is."""
+    return rc == (RT_OK if rta.device_count() > 0 else RT_ERR_NO_DEVICE)
+
+
+def test_flat_description_checks(rta):
+    sc, a, d = _flat(rta)
+    rc, msg = _create(rta, d)
+    assert _good(rta, rc), msg
+    hip, _ = rta.load_libraries()
+    assert hip.rt_scene_create(None, 0, None) == RT_ERR_INVALID
+
+    def broken(field, value, where=None):
+        sc2, a2, d2 = _flat(rta)
+        if where is None:
+            setattr(d2, field, value)
+        else:
+            a2[where][field][value[0]] = value[1]
+        rc, msg = _create(rta, d2)
+        return rc, msg
+
+    assert broken("root_ref", 10 ** 6)[0] == RT_ERR_INVALID
+    assert broken("n_tris", 0)[0] == RT_ERR_INVALID
+    assert broken("n_materials", 0)[0] == RT_ERR_INVALID
+    assert broken("n_lights", 16)[0] == RT_ERR_LIMIT
+    rc, msg = broken("lref", (3, 10 ** 6), "FLAT_PAIRS")
+    assert rc == RT_ERR_INVALID and "child ref" in msg
+    rc, msg = broken("material", (5, 99), "FLAT_TRIS")
+    assert rc == RT_ERR_INVALID and "material" in msg
+    rc, msg = broken("tri_id", (len(a["FLAT_TRIS"]) - 1, 7), "FLAT_TRIS")  # the last triangle no longer ends a leaf
+    assert rc == RT_ERR_INVALID and "leaf" in msg
+    rc, msg = broken("type", (0, 42), "MATERIALS")
+    assert rc == RT_ERR_INVALID and "material type" in msg
+    rc, msg = broken("kind", (0, 9), "LIGHTS")
+    assert rc == RT_ERR_INVALID and "light" in msg
+
+
+def test_two_level_description_checks(rta):
+    sc, a, d, t = _two_level(rta)
+    rc, msg = _create(rta, d, t)
+    assert _good(rta, rc), msg
+
+    def broken(edit):
+        sc2, a2, d2, t2 = _two_level(rta)
+        edit(a2, d2, t2)
+        return _create(rta, d2, t2)
+
+    rc, msg = broken(lambda a2, d2, t2: setattr(t2, "n_instances", 0))
+    assert rc == RT_ERR_INVALID and "instances" in msg
+    rc, msg = broken(lambda a2, d2, t2: a2["TLAS_PAIRS"]["rref"].__setitem__(0, ~(10 ** 6)))
+    assert rc == RT_ERR_INVALID and "TLAS child ref" in msg
+    rc, msg = broken(lambda a2, d2, t2: setattr(t2, "root_ref", 10 ** 6))
+    assert rc == RT_ERR_INVALID and "root_ref" in msg
+    rc, msg = broken(lambda a2, d2, t2: a2["INSTANCES"]["geometry"].__setitem__(1, 17))
+    assert rc == RT_ERR_INVALID and "geometry" in msg
+    rc, msg = broken(lambda a2, d2, t2: a2["INSTANCES"]["material"].__setitem__(2, 99))
+    assert rc == RT_ERR_INVALID and "material" in msg
+    mesh_i = int(np.argmax(a["INSTANCES"]["geometry"] == 0))
+    rc, msg = broken(lambda a2, d2, t2: a2["INSTANCES"]["blas_root"].__setitem__(mesh_i, 10 ** 6))
+    assert rc == RT_ERR_INVALID and "blas_root" in msg
+    rc, msg = broken(lambda a2, d2, t2: a2["LIGHTS"]["kind"].__setitem__(0, 1))
+    assert rc == RT_ERR_INVALID and "rectangles" in msg
+    hip, _ = rta.load_libraries()
+    out = C.c_void_p()
+    assert hip.rt_scene_create_instanced(C.byref(d), None, 0, C.byref(out)) == RT_ERR_INVALID
+
+
+def test_calls_on_null_scene(rta):
+    hip, _ = rta.load_libraries()
+    rays = np.zeros(4, rta.RAY)
+    hits = np.zeros(4, rta.HIT)
+    assert hip.rt_trace_closest(None, rays.ctypes.data, 4, hits.ctypes.data) == RT_ERR_INVALID
+    assert hip.rt_trace_closest_indexed(None, rays.ctypes.data, 4, hits.ctypes.data, None) == RT_ERR_INVALID
+    assert hip.rt_trace_any(None, rays.ctypes.data, None, 4, None) == RT_ERR_INVALID
+    assert hip.rt_render(None, None, None, None, None) == RT_ERR_INVALID
+    assert hip.rt_resolve(None, None, 0, 0, 0, 2.2, None) == RT_ERR_INVALID
+    assert hip.rt_scene_sync(None) == RT_ERR_INVALID
+    assert "null" in rta.last_error() or "bad" in rta.last_error()
+
+
+@pytest.mark.gpu
+def test_render_argument_checks(rta, gpu):
+    sc = scenes.quad_room(rta)
+    sc.build()
+    sc.upload(gpu)
+    cam = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, 32, 32)
+    for kw, code in (({"tile": (0, 0, 40, 32)}, RT_ERR_INVALID), ({"tile": (8, 8, 8, 16)}, RT_ERR_INVALID), ({"spp_total": 2}, RT_ERR_INVALID),
+                     ({"max_depth": 0}, RT_ERR_LIMIT), ({"max_depth": 64}, RT_ERR_LIMIT)):
+        args = dict(spp=4, max_depth=4)
+        args.update(kw)
+        with pytest.raises(rta.RtError, match=f"rt error {code}"):
+            sc.render(cam, 32, 32, **args)
+    img, st = sc.render(cam, 32, 32, spp=4, max_depth=4)  # the handle is still usable after the refusals
+    assert st["paths"] == 32 * 32 * 4 and np.isfinite(img).all()
