@@ -99,7 +99,8 @@ typedef struct rt_tri_normals {
 /* Material table entry (Material.h / Material.cpp classes flattened to a tag
  * + parameters), 80 B. */
 enum {
-    RT_MAT_MATTE = 0,            /* MatteMaterial      Material.h:64-92   c0 = albedo                  */
+    RT_MAT_MATTE = 0,            /* MatteMaterial      Material.h:64-92   c0 = albedo (ConstantTexture); CheckeredTexture
+                                    (Material.h:25-41): c0 = even, c1 = odd, s0 = its grid = PI / the constructor's argument (0 = constant) */
     RT_MAT_MICROFACET_GGX = 1,   /* Microfacet         Material.cpp:4-109 s0 = roughness               */
     RT_MAT_MICROFACET_BECKMANN = 2, /* (new, no reference arithmetic)     s0 = roughness               */
     RT_MAT_EMISSIVE = 3,         /* EmissiveMaterial   Material.h:274-284 c0 = emit                    */

@@ -677,6 +677,7 @@ inline V3 cosine_sample(RndSrc& r) { // Utils.h:70-83
 struct Surf { // Intersection, Def.h:11-40
     V3 point, normal;
     bool front_face = true;
+    float u = 0, v = 0; // a Rectangle's si->u, si->v; 0 where the Geometry writes none (defined here: the reference leaves them stale)
 };
 
 struct Scatter {
@@ -925,7 +926,17 @@ V3 mat_eval(const orc_material* m, const Surf& si, const V3& in_dir, const V3& o
     switch (m->type) {
     case 0: { // MatteMaterial::Eval, Material.h:81-88
         *pdf = fmax_sel(dot(n, out_dir), 0.f) / kPi;
-        return (V3(m->c0) * fmax_sel(dot(n, out_dir), 0.f)) / kPi;
+        V3 albedo(m->c0); // ConstantTexture::sample, Material.h:19-21
+        if (m->s[0] != 0) { // CheckeredTexture::sample, Material.h:29-36 (s0 = grid = PI / the constructor's argument, c0 even, c1 odd)
+            const float grid = m->s[0];
+            auto modulo = [](float a, float b) { // Math.h:39-42
+                float r = std::fmod(a, b);
+                return (r < 0) ? r + b : r;
+            };
+            bool odd_ = (modulo(si.u, grid) < grid * 0.5) ^ (modulo(si.v, grid) < grid * 0.5);
+            albedo = odd_ ? V3(m->c1) : V3(m->c0);
+        }
+        return (albedo * fmax_sel(dot(n, out_dir), 0.f)) / kPi;
     }
     case 1:
     case 2: { // Microfacet::Eval, Material.cpp:87-98
@@ -1455,6 +1466,8 @@ V3 radiance(Ctx& c, const orc_camera* cam, const orc_options* opt, int x, int y,
             si.point = gh.point;
             si.normal = gh.normal;
             si.front_face = gh.front_face;
+            si.u = I.geometry != 0 ? gh.u : 0.f; // (a mesh hit's gh.u, gh.v are the triangle's barycentrics, reported only)
+            si.v = I.geometry != 0 ? gh.v : 0.f;
             mat = &s->materials[I.material]; // Object.h:387
             hit_area = I.area;
         } else {

@@ -963,6 +963,7 @@ RT_DEV V3 cosine_sample(Rng& r) { // Utils.h:70-83
 struct Surf { // Intersection, Def.h:11-40
     V3 point, normal;
     bool front_face;
+    float u, v; // texture coordinates: a Rectangle's si->u, si->v (Object.h:116-117); 0 where the reference's Geometry writes none
 };
 struct Scatter {
     V3 origin, dir, f;
@@ -1177,6 +1178,19 @@ RT_DEV V3 uber_metal(const UberP& u, const V3& V, const V3& L, const V3& H, floa
 
 RT_DEV V3 mat_emitted(const rt_material& m) { return m.type == RT_MAT_EMISSIVE ? V3(m.c0) : V3(0.f); }
 
+// albedo->sample(si.u, si.v, si.point) of MatteMaterial::Eval (Material.h:84): ConstantTexture (Material.h:13-24) or,
+// when s0 = its grid (PI / the constructor's argument) is set, CheckeredTexture::sample (Material.h:29-36)
+RT_DEV float modulo_f(float a, float b) { // Math.h:39-42
+    const float r = fmodf(a, b);
+    return (r < 0.f) ? r + b : r;
+}
+RT_DEV V3 matte_albedo(const rt_material& m, const Surf& si) {
+    const float grid = m.s[0];
+    if (grid == 0.f) return V3(m.c0);
+    const bool odd = ((double)modulo_f(si.u, grid) < (double)grid * 0.5) ^ ((double)modulo_f(si.v, grid) < (double)grid * 0.5);
+    return odd ? V3(m.c1) : V3(m.c0);
+}
+
 // Material::Eval
 RT_DEV V3 mat_eval(const rt_material& m, const Surf& si, const V3& in_dir, const V3& out_dir, float* pdf) {
     const V3 n = si.normal;
@@ -1184,7 +1198,7 @@ RT_DEV V3 mat_eval(const rt_material& m, const Surf& si, const V3& in_dir, const
     case RT_MAT_MATTE: { // Material.h:81-88
         float c = fmax_sel(dot(n, out_dir), 0.f);
         *pdf = c / kPi;
-        return (V3(m.c0) * c) / kPi;
+        return (matte_albedo(m, si) * c) / kPi;
     }
     case RT_MAT_MICROFACET_GGX:
     case RT_MAT_MICROFACET_BECKMANN: { // Material.cpp:87-98

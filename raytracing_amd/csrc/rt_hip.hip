@@ -355,9 +355,12 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
             N = normalize(N);
             si.front_face = dot(md, N) < 0.f;
             nm = si.front_face ? N : -N;
+            si.u = si.v = 0.f; // TriangleMesh::intersect writes no si->u / si->v (Object.h:346-356)
         } else {
             nm = V3(g4);
             si.front_face = (iw & RT_HIT2_FRONT) != 0;
+            si.u = h4.z; // the Rectangle's (Object.h:116-117); 0 for the other primitives
+            si.v = h4.w;
         }
         si.point = xf_point(m2w, mo + md * h4.y);
         si.normal = normalize(xf_world_normal(w2m, nm));
@@ -376,6 +379,7 @@ RT_DEV void shade_item(const SceneView& sc, const TB& tb, const Wave& w, const P
         N = normalize(N);
         si.front_face = dot(rd, N) < 0.f;
         si.normal = si.front_face ? N : -N;
+        si.u = si.v = 0.f;
         hit_area = light_id >= 0 ? sc.lights[light_id].area : 0.f; // Geometry::area() default, Object.h:18-20
     }
     rt_material mat = sc.materials[mat_id];

@@ -13,6 +13,8 @@ class Texture { // Material.h:7-12
 public:
     virtual ~Texture() {}
     virtual vec3 sample(float u, float v, vec3 point) const = 0;
+    // c0 / c1 / s0 of an RT_MAT_MATTE record (include/rt_hip.h): the shade kernel samples the texture per hit
+    virtual void describe(rt_material* m) const = 0;
 };
 class ConstantTexture : public Texture { // Material.h:13-24
 public:
@@ -20,6 +22,11 @@ public:
     ConstantTexture(float r, float g, float b) : color(r, g, b) {}
     explicit ConstantTexture(float rgb) : color(rgb) {}
     vec3 sample(float, float, vec3) const override { return color; }
+    void describe(rt_material* m) const override {
+        m->c0[0] = color.x;
+        m->c0[1] = color.y;
+        m->c0[2] = color.z;
+    }
 
 private:
     vec3 color;
@@ -27,10 +34,16 @@ private:
 
 // Material.h:25-41.  `grid` is stored as PI / grid and the cell test compares modulo(u, grid) with half of it, as the
 // reference does.  (Triangle-mesh hits carry no uv — Object.h:350-355 never writes si.u / si.v — so on the mesh path
-// a checkered albedo evaluates at u = v = 0: its `even` colour.)
+// a checkered albedo evaluates at u = v = 0: its `even` colour; a Rectangle instance of a two-level scene supplies its
+// own si->u, si->v, Object.h:116-117.)
 class CheckeredTexture : public Texture {
 public:
     CheckeredTexture(vec3 even_, vec3 odd_, float grid_ = 0.25f) : even(even_), odd(odd_), grid(3.14159265358979323846f / grid_) {}
+    static CheckeredTexture* from_record(vec3 even_, vec3 odd_, float stored_grid) { // the value describe() wrote, bit for bit
+        CheckeredTexture* t = new CheckeredTexture(even_, odd_);
+        t->grid = stored_grid;
+        return t;
+    }
     vec3 sample(float u, float v, vec3) const override {
         auto modulo = [](float a, float b) { // Math.h:39-42
             float r = std::fmod(a, b);
@@ -38,6 +51,11 @@ public:
         };
         const bool odd_cell = (modulo(u, grid) < grid * 0.5) ^ (modulo(v, grid) < grid * 0.5);
         return odd_cell ? odd : even;
+    }
+    void describe(rt_material* m) const override {
+        m->c0[0] = even.x; m->c0[1] = even.y; m->c0[2] = even.z;
+        m->c1[0] = odd.x; m->c1[1] = odd.y; m->c1[2] = odd.z;
+        m->s[0] = grid;
     }
 
 private:
@@ -71,9 +89,7 @@ public:
     ~MatteMaterial() override { delete albedo; }
     rt_material flatten() const override {
         rt_material m = blank(RT_MAT_MATTE);
-        // mesh hits never write si.u/si.v (Object.h:350-355), so the texture is
-        // sampled at (0, 0, origin) once
-        put(m.c0, albedo->sample(0, 0, vec3(0)));
+        albedo->describe(&m); // sampled per hit on the GPU: a Rectangle instance supplies (u, v), every other hit (0, 0)
         return m;
     }
 

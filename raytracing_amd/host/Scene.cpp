@@ -717,7 +717,9 @@ bool write_bmp(const std::string& path, int w, int h, const uint8_t* rgb) {
 Material* material_from_record(const rt_material& r) {
     vec3 c0(r.c0[0], r.c0[1], r.c0[2]), c1(r.c1[0], r.c1[1], r.c1[2]);
     switch (r.type) {
-    case RT_MAT_MATTE: return new MatteMaterial(new ConstantTexture(c0));
+    case RT_MAT_MATTE:
+        if (r.s[0] != 0.f) return new MatteMaterial(CheckeredTexture::from_record(c0, c1, r.s[0]));
+        return new MatteMaterial(new ConstantTexture(c0));
     case RT_MAT_MICROFACET_GGX: return new Microfacet(nullptr, r.s[0], r.s[1]);
     case RT_MAT_MICROFACET_BECKMANN: return new BeckmannMicrofacet(nullptr, r.s[0], r.s[1]);
     case RT_MAT_EMISSIVE: return new EmissiveMaterial(c0);

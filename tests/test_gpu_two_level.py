@@ -206,3 +206,43 @@ def test_cpp_scene_script_renders(gpu, tmp_path):
     assert data[:2] == b"BM" and len(data) == 54 + 96 * 3 * 64
     px = np.frombuffer(data[54:], np.uint8)
     assert px.mean() > 10 and px.std() > 5
+
+
+def _checker_scene(rta):
+    """A Rectangle with MatteMaterial(CheckeredTexture) (the back wall of main.cpp:573-580), lit by a Rectangle light."""
+    sc = rta.Scene()
+    grid = np.float32(np.pi) / np.float32(0.1)  # CheckeredTexture(even, odd, 0.1) stores PI / grid (Material.h:28)
+    checker = sc.add_material(rta.material(rta.MAT_MATTE, (0.1, 0.1, 0.8), (1, 1, 1), s=(grid,)))
+    grey = sc.add_material(rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5)))
+    emit = sc.add_material(rta.material(rta.MAT_EMISSIVE, (17, 12, 4)))
+    sc.add_primitive_instance(rta.GEO_RECTANGLE, (0, 0, 1, 2.0, 2.0), checker, scenes._trs((0, 1, -1)))
+    sc.add_primitive_instance(rta.GEO_RECTANGLE, (0, 1, 0, 2.0, 2.0), grey, scenes._trs((0, 0, 0)))
+    sc.add_primitive_instance(rta.GEO_SPHERE, (0.25,), checker, scenes._trs((0.4, 0.25, 0.2)))  # no uv: the `even` colour
+    sc.add_primitive_instance(rta.GEO_RECTANGLE, (0, -1, 0, 0.6, 0.6), emit, scenes._trs((0, 1.98, 0)), light=True)
+    sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
+    return sc
+
+
+def test_checkered_texture_on_a_rectangle(rta, orc, gpu):
+    """MatteMaterial::Eval samples its texture at the hit's (u, v) (Material.h:84); a Rectangle instance supplies them
+    (Object.h:116-117), so CheckeredTexture shows — with grid = PI / 0.1 against u, v in [-1, 1]: the four quadrants."""
+    sc = _checker_scene(rta)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc)
+    w, h = 96, 96
+    cam = rta.camera(rta.look_at((0.0, 1.0, 3.0), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, w, h)
+    img, st = sc.render(cam, w, h, spp=16, max_depth=3, seed=4)
+    ref, oc = orc.render(osc, cam, w, h, 16, 3, seed=4)
+    _compare(img, ref)
+    # the wall's quadrants: blue where u and v have the same sign (even), white where they differ (odd)
+    # (the wall covers rows and columns 19..77 of the 96 x 96 raster, its centre at (48, 48); u runs along +x, v along +y
+    # and raster rows are not flipped before rt_resolve, so low row numbers are the wall's lower half)
+    q = {(su, sv): img[rows, cols].mean((0, 1)) for sv, rows in ((-1, slice(25, 42)), (1, slice(54, 71)))
+         for su, cols in ((-1, slice(25, 42)), (1, slice(54, 71)))}
+    blue = lambda c: c[2] / c[0]
+    for su, sv in ((1, 1), (-1, -1)):  # same signs: both cell tests agree -> even (blue); opposite signs -> odd (white)
+        assert blue(q[(su, sv)]) > 2.5 * blue(q[(-su, sv)]) and blue(q[(su, sv)]) > 2.5 * blue(q[(su, -sv)]), q
+    # host classes give the record back bit for bit
+    m = sc.array(rta.ARR_MATERIALS)[0]
+    assert m["s"][0] == np.float32(np.pi) / np.float32(0.1) and tuple(m["c1"]) == (1, 1, 1)
