@@ -246,3 +246,65 @@ def test_checkered_texture_on_a_rectangle(rta, orc, gpu):
     # host classes give the record back bit for bit
     m = sc.array(rta.ARR_MATERIALS)[0]
     assert m["s"][0] == np.float32(np.pi) / np.float32(0.1) and tuple(m["c1"]) == (1, 1, 1)
+
+
+def _random_affine_scene(rta, seed, n=40):
+    """Instances of every geometry kind under random AFFINE transforms: rotation x non-uniform scale x shear + translation
+    (Transform::to_world_normal's inverse-transpose matters here), overlapping one another."""
+    rng = np.random.default_rng(seed)
+    sc = rta.Scene()
+    mats = [sc.add_material(rta.material(rta.MAT_MATTE, rng.uniform(0.2, 0.9, 3))), sc.add_material(rta.material(rta.MAT_GGX, s=(0.4, 0.0))),
+            sc.add_material(rta.material(rta.MAT_DISNEY_DIFFUSE, (0.7, 0.6, 0.5), s=(0.5, 0.3)))]
+    v, t = scenes.uv_sphere(rta, 8, 12)
+    mesh = sc.new_triangle_mesh(v, t)
+    kinds = [rta.GEO_MESH, rta.GEO_SPHERE, rta.GEO_RECTANGLE, rta.GEO_DISK, rta.GEO_BOX, rta.GEO_CYLINDER]
+    for i in range(n):
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        shear = np.eye(3)
+        shear[0, 1] = rng.uniform(-0.4, 0.4)
+        shear[2, 0] = rng.uniform(-0.3, 0.3)
+        m = np.eye(4)
+        m[:3, :3] = q @ np.diag(rng.uniform(0.15, 0.6, 3)) @ shear
+        m[:3, 3] = rng.uniform(-1.0, 1.0, 3)
+        m16 = m.T.reshape(-1).astype(np.float32)
+        kind, mat = kinds[i % 6], mats[i % 3]
+        if kind == rta.GEO_MESH:
+            sc.add_mesh_instance(mesh, mat, m16)
+        else:
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            params = {rta.GEO_SPHERE: (rng.uniform(0.3, 1.0),), rta.GEO_RECTANGLE: (*nrm, rng.uniform(0.5, 2), rng.uniform(0.5, 2)),
+                      rta.GEO_DISK: (*nrm, rng.uniform(0.5, 1.2), rng.uniform(0.0, 0.3)), rta.GEO_BOX: tuple(rng.uniform(0.4, 1.5, 3)),
+                      rta.GEO_CYLINDER: (rng.uniform(0.2, 0.8), rng.uniform(0.5, 2.0))}[kind]
+            sc.add_primitive_instance(kind, params, mat, m16)
+    sc.set_env(np.full((8, 16, 3), 0.4, np.float32))
+    return sc
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_affine_instances(rta, orc, gpu, seed):
+    sc = _random_affine_scene(rta, seed)
+    sc.build()
+    sc.upload(gpu)
+    osc = orc.two_level_scene_from_host(sc, own_bvh=True)
+    rng = np.random.default_rng(seed + 100)
+    n = 30000
+    rays = np.zeros(n, orc.RAY)
+    rays["o"] = rng.uniform(-1.6, 1.6, (n, 3))  # many origins lie inside boxes, spheres and cylinders
+    d = rng.normal(size=(n, 3))
+    rays["d"] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays["d"][::50, 1] = 0.0  # axis-parallel components: the select-form slab test and 0 / 0 in the Box test
+    rays["d"][::75, 0] = 0.0
+    ref, ridx, rn, rff = orc.closest_hit2(osc, rays)
+    hits, idx = sc.trace_closest_indexed(rays)
+    assert np.array_equal(idx, ridx), f"{(idx != ridx).sum()} instance indices differ"
+    assert hits.tobytes() == ref.tobytes()
+    inst = sc.array(rta.ARR_INSTANCES)
+    assert set(inst["geometry"][idx[idx >= 0]]) == set(range(6)) and 0.15 < (idx >= 0).mean() < 1.0
+    tmax = (np.where(np.isfinite(ref["t"]), ref["t"], 1.0) * rng.choice([0.3, 0.98, 1.02, 3.0], n)).astype(np.float32)
+    assert np.array_equal(sc.trace_any(rays, tmax), orc.any_hit2(osc, rays, tmax))
+    # normals and front faces through the shading path: a primary-hit-only render equals the oracle's
+    cam = rta.camera(rta.look_at((0.0, 0.3, 4.5), (0.0, 0.0, 0.0), (0, 1, 0)), 40.0, 64, 48)
+    img, _ = sc.render(cam, 64, 48, spp=4, max_depth=3, seed=seed)
+    ref_img, _ = orc.render(osc, cam, 64, 48, 4, 3, seed=seed)
+    _compare(img, ref_img)
