@@ -18,10 +18,8 @@ import scenes
 sc = scenes.cornellbox(rta)
 sc.build()
 sc.upload(0)
-W, H = 1920, 1080
-cam_view = sc.info()
 rng = np.random.default_rng(1)
-# primary-hit points from a coarse grid of camera rays, then cosine-ish bounce directions
+# first hits of random rays inside the room, then uniformly random bounce directions from the hit points
 n = 4_000_000
 o = rng.uniform((-1.5, 0.1, -1.5), (1.5, 3.0, 1.5), (n, 3)).astype(np.float32)
 d = rng.normal(size=(n, 3)).astype(np.float32)
