@@ -244,8 +244,8 @@ inline bool mesh_traverse(const orc_mesh* s, const V3& o, const V3& d, float tmi
     while (sp > 0) {
         const orc_node* nd = &s->nodes[stack[--sp]];
         if (nd->count != -1) {
-            leaf++;
             for (int i = 0; i < nd->count; i++) {
+                leaf++; // visit statistics: one unit per triangle tested (= per leaf with the reference's one-triangle leaves)
                 V3 bary_tmp;
                 float t_tmp = -1;
                 int tri = s->indices[nd->left_node + i];

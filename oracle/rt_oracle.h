@@ -44,7 +44,7 @@ typedef struct orc_node { /* BVH.h:15-21 */
 
 typedef struct orc_ray { float o[3]; float d[3]; } orc_ray;
 typedef struct orc_hit { int32_t tri; float t; float u; float v; } orc_hit;
-typedef struct orc_visits { int32_t inner; int32_t leaf; } orc_visits;
+typedef struct orc_visits { int32_t inner; int32_t leaf; } orc_visits; /* inner nodes visited; triangles tested (= leaves visited when leaves hold one triangle) */
 
 /* same tag values and parameter slots as the product's material table */
 typedef struct orc_material {

@@ -161,3 +161,26 @@ def test_light_directed_segments_match_the_reference_walk(rta, orc, cornell):
     want = orc.any_hit(osc, seg, tmax)
     assert np.array_equal(got, want), np.count_nonzero(got != want)
     assert 0.03 < want.mean() < 0.97  # both answers are well represented (1.7 M segments, ~10 % unoccluded)
+
+
+def test_two_triangles_per_leaf_same_hits(rta, orc, gpu):
+    """bench.py walks cornellbox under BVH::build(bounds, 2, BVH_SAH) (the reference's builder, max_per_node = 2): the hits
+    are those of the one-triangle-per-leaf tree its TriangleMesh builds (Object.cpp:21), and the oracle's on either tree."""
+    one, two = scenes.cornellbox(rta), scenes.cornellbox(rta)
+    one.build(max_per_leaf=1)
+    two.build(max_per_leaf=2)
+    assert len(two.array(rta.ARR_FLAT_PAIRS)) < 0.75 * len(one.array(rta.ARR_FLAT_PAIRS))
+    one.upload(gpu)
+    two.upload(gpu)
+    cam = scenes.cornell_camera(rta, one, 160, 90)
+    rays = np.concatenate([orc.camera_rays(cam, 160, 90, 2, 8), scenes.random_rays(40000, 77, lo=(-1.7, 0, -1.7), hi=(1.7, 3.4, 1.7))])
+    h1, h2 = one.trace_closest(rays), two.trace_closest(rays)
+    ref, _ = orc.closest_hit(orc.scene_from_host(two), rays)
+    assert h2.tobytes() == ref.tobytes()
+    assert np.array_equal(h1["tri"], h2["tri"]) and np.array_equal(h1["t"], h2["t"]) and np.array_equal(h1["u"], h2["u"])
+    tmax = (np.random.default_rng(5).random(len(rays)) * 3).astype(np.float32)
+    assert np.array_equal(one.trace_any(rays, tmax), two.trace_any(rays, tmax))
+    assert np.array_equal(two.trace_any(rays, tmax), orc.any_hit(orc.scene_from_host(two), rays, tmax))
+    img1, _ = one.render(cam, 160, 90, spp=4, max_depth=6, seed=9)
+    img2, _ = two.render(cam, 160, 90, spp=4, max_depth=6, seed=9)
+    assert np.array_equal(img1, img2)  # the same paths, the same arithmetic: the tree changes no pixel

@@ -2,7 +2,8 @@
 """Measures <inner-node visits> and <leaf visits> per ray on the bench workload by instrumenting the CPU ORACLE's
 traversal, and writes the algorithmic bytes per ray that bench.py's roofline uses:
     B_ray = 64 * <inner> + 52 * <leaf> + 48
-(64 B child-pair record, 52 B = 4 B index + 48 B triangle, 48 B = 32 B ray read + 16 B hit write).
+(64 B child-pair record, 52 B = 4 B index + 48 B triangle per triangle tested — <leaf> counts triangles, which is leaves
+when a leaf holds one —, 48 B = 32 B ray read + 16 B hit write).
 The full 1080p view is sampled on a 480x270 raster (same camera, same materials, depth 8): the visit statistics are a
 property of the ray distribution, not of the resolution.  Test/measurement infrastructure: uses oracle/."""
 import json
@@ -17,13 +18,14 @@ import raytracing_amd as rta  # noqa: E402
 import scenes  # noqa: E402
 
 WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "cornellbox"
-if WORKLOAD == "cornellbox":
+if WORKLOAD in ("cornellbox", "cornellbox_leaf2"):  # _leaf2: BVH::build(bounds, 2, BVH_SAH) — the tree bench.py walks by default
     W, H, SPP, DEPTH = 480, 270, 8, 8
+    per_leaf = 2 if WORKLOAD.endswith("leaf2") else 1
     sc = scenes.cornellbox(rta)
-    sc.build()
+    sc.build(max_per_leaf=per_leaf)
     cam = scenes.cornell_camera(rta, sc, W, H)
-    label = f"cornellbox.glb GGX+Beckmann, depth {DEPTH}, camera of the file"
-    name = "visits_cornellbox_1080p_d8.json"
+    label = f"cornellbox.glb GGX+Beckmann, depth {DEPTH}, camera of the file, BVH::build(bounds, {per_leaf}, BVH_SAH)"
+    name = "visits_cornellbox_1080p_d8.json" if per_leaf == 1 else "visits_cornellbox_1080p_d8_leaf2.json"
 elif WORKLOAD == "spheres10m":  # BASELINE config 4 geometry: 9.6 M triangles (the SAH build takes about a minute on 8 cores)
     W, H, SPP, DEPTH = 480, 270, 1, 8
     import numpy as np
