@@ -80,7 +80,8 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--max-per-leaf", type=int, default=2, help="cornellbox: max_per_node of BVH::build (1 = what the reference's TriangleMesh passes)")
+    ap.add_argument("--max-per-leaf", type=int, default=None, help="max_per_node of BVH::build (1 = what the reference's TriangleMesh passes); "
+                    "default: 2 for cornellbox, 1 for the other flat workloads")
     ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m", "instanced5m", "instanced5m_flat"], default="cornellbox",
                     help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow "
                          "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces; "
@@ -115,6 +116,9 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    probe_leaf = args.max_per_leaf is not None and args.workload != "cornellbox"  # another tree than the workload's visit statistics describe
+    if args.max_per_leaf is None:
+        args.max_per_leaf = 2 if args.workload == "cornellbox" else 1
     # ---- scene: load, build the BVH on the host, flatten, upload once
     t0 = time.time()
     depth = DEPTH
@@ -133,7 +137,7 @@ def main():
             visits_json = ""  # no visit statistics for this tree: no roofline
     elif args.workload == "random1m":  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
         sc = scenes.random_triangles(rta, 1_000_000)
-        sc.build()  # the reference's SAH builder (multi-threaded, same output)
+        sc.build(max_per_leaf=args.max_per_leaf)  # the reference's SAH builder (multi-threaded, same output)
         cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
         depth = 1
         visits_json = os.path.join(ROOT, "profiles", "visits_random1m_1080p_d1.json")
@@ -146,14 +150,14 @@ def main():
         label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), rectangle light + uniform environment"
     elif args.workload == "instanced5m_flat":  # the same surfaces flattened into one 5 M-triangle world-space mesh (Scene::add_instance)
         sc = scenes.legacy_instanced_flat(rta)
-        sc.build()
+        sc.build(max_per_leaf=args.max_per_leaf)
         cam = scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
         visits_json = os.path.join(ROOT, "profiles", "visits_instanced5m_flat_1080p_d8.json")
         label = "room + one 99 856-triangle mesh x 50, FLATTENED into one 5 M-triangle mesh, rectangle light + uniform environment"
     else:  # BASELINE configs[3] geometry, one GPU's share: 614 MB of pair records + 922 MB of triangles and normals, beyond every cache
         WIDTH, HEIGHT = 3840, 2160
         sc = scenes.sphere_field(rta)
-        sc.build()
+        sc.build(max_per_leaf=args.max_per_leaf)
         cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
         sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
         visits_json = os.path.join(ROOT, "profiles", "visits_spheres10m_4k_d8.json")
@@ -238,7 +242,7 @@ def main():
             },
         }
         # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
-        visits = json.load(open(visits_json)) if os.path.exists(visits_json) else None
+        visits = json.load(open(visits_json)) if os.path.exists(visits_json) and not probe_leaf else None
         kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"  # (k_closest2 / k_shadow2 on a two-level scene)
         if visits and max(stats["ms_closest"], stats["ms_shadow"]) > 0:
             v = visits["closest" if kern == "k_closest" else "shadow"]
