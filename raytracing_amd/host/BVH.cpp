@@ -18,7 +18,8 @@
 // their 300 candidate planes over the threads (each cost is computed
 // independently, the arg-min is taken in the reference's axis/plane order);
 // ranges below a threshold become independent tasks that write their own
-// block.  Nodes and indices are bit-identical to the one-thread build.
+// block.  Nodes and indices are bit-identical to the one-thread build.  Every other case (larger leaves, BVH_MIDDLE)
+// goes through run_threaded_general: subtrees built into private arrays and renumbered afterwards.
 #include "BVH.h"
 
 #include <algorithm>
@@ -122,6 +123,107 @@ public:
         for (auto& th : pool) th.join();
     }
 
+    // Any leaf size, any strategy: subtree sizes are not known in advance, so the build runs in three steps.  (1) The top
+    // of the tree, one node at a time with the candidate planes spread over the threads, down to ranges of at most
+    // `small` primitives.  (2) Every such range is built by one thread into its OWN node array, numbered as run() numbers
+    // a tree (root 0, children allocated in pairs, left subtree before the right one).  (3) One pass in the recursion's
+    // order gives every node its final index: a top node allocates its pair and descends left then right; a range's local
+    // nodes 1.. follow as one block, local index i -> base + i - 1.  Same nodes and indices as run(), bit for bit.
+    void run_threaded_general(int n_threads, int small) {
+        struct Top {
+            int begin, end, left, right; // children: indices into `top`, -1 = this range is a task
+            BVHNode node;
+        };
+        std::vector<Top> top;
+        top.push_back({0, (int)prims_.size(), -1, -1, BVHNode()});
+        std::vector<BVHNode> scratch(1);
+        std::vector<int> task_of; // indices into `top` of the ranges built in step 2
+        for (size_t i = 0; i < top.size(); i++) {
+            const int b = top[i].begin, e = top[i].end;
+            if (e - b <= small) {
+                task_of.push_back((int)i);
+                continue;
+            }
+            int split = 0;
+            scratch[0] = BVHNode();
+            if (!split_node(scratch, Range{b, e, 0}, &split, n_threads)) { // (only when leaf_size_ >= small)
+                top[i].node = scratch[0];
+                continue;
+            }
+            top[i].node = scratch[0];
+            top[i].left = (int)top.size();
+            top[i].right = (int)top.size() + 1;
+            top.push_back({b, split, -1, -1, BVHNode()});
+            top.push_back({split, e, -1, -1, BVHNode()});
+        }
+        std::vector<std::vector<BVHNode>> local(task_of.size());
+        std::atomic<size_t> cursor{0};
+        auto worker = [&]() {
+            std::vector<Range> todo;
+            for (;;) {
+                const size_t k = cursor.fetch_add(1);
+                if (k >= task_of.size()) return;
+                std::vector<BVHNode>& nodes = local[k];
+                nodes.reserve(2 * (size_t)(top[task_of[k]].end - top[task_of[k]].begin));
+                nodes.emplace_back();
+                todo.push_back({top[task_of[k]].begin, top[task_of[k]].end, 0});
+                while (!todo.empty()) {
+                    Range r = todo.back();
+                    todo.pop_back();
+                    int split = 0;
+                    if (!split_node(nodes, r, &split, 1)) continue;
+                    const int left = (int)nodes.size();
+                    nodes.emplace_back();
+                    nodes.emplace_back();
+                    nodes[r.node].count = BVH_BRANCH;
+                    nodes[r.node].left_node = left;
+                    todo.push_back({split, r.end, left + 1});
+                    todo.push_back({r.begin, split, left});
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int i = 1; i < n_threads; i++) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+        std::vector<int> local_of(top.size(), -1);
+        for (size_t k = 0; k < task_of.size(); k++) local_of[task_of[k]] = (int)k;
+        // step 3: final numbering in the recursion's order
+        nodes_.clear();
+        nodes_.emplace_back();
+        struct Place {
+            int top, node;
+        };
+        std::vector<Place> todo;
+        todo.push_back({0, 0});
+        while (!todo.empty()) {
+            const Place p = todo.back();
+            todo.pop_back();
+            const Top& t = top[p.top];
+            if (local_of[p.top] >= 0) {
+                const std::vector<BVHNode>& nodes = local[local_of[p.top]];
+                const int base = (int)nodes_.size(); // local node i >= 1 -> base + i - 1
+                nodes_[p.node] = nodes[0];
+                if (nodes[0].count == BVH_BRANCH) nodes_[p.node].left_node = base + nodes[0].left_node - 1;
+                for (size_t i = 1; i < nodes.size(); i++) {
+                    BVHNode n = nodes[i];
+                    if (n.count == BVH_BRANCH) n.left_node = base + n.left_node - 1;
+                    nodes_.push_back(n);
+                }
+                continue;
+            }
+            nodes_[p.node] = t.node;
+            if (t.left < 0) continue; // a leaf made in step 1
+            const int left = (int)nodes_.size();
+            nodes_.emplace_back();
+            nodes_.emplace_back();
+            nodes_[p.node].count = BVH_BRANCH;
+            nodes_[p.node].left_node = left;
+            todo.push_back({t.right, left + 1});
+            todo.push_back({t.left, left});
+        }
+    }
+
     std::vector<BVHNode> nodes_;
     std::vector<int> order_;
 
@@ -159,8 +261,9 @@ private:
     }
 
     // returns false when the range became a leaf
-    bool split_node(const Range& r, int* split, int n_threads = 1) {
-        BVHNode& node = nodes_[r.node];
+    bool split_node(const Range& r, int* split, int n_threads = 1) { return split_node(nodes_, r, split, n_threads); }
+    bool split_node(std::vector<BVHNode>& nodes, const Range& r, int* split, int n_threads) {
+        BVHNode& node = nodes[r.node];
         node.aabb = enclose(r.begin, r.end);
         const int n = r.end - r.begin;
         if (n <= leaf_size_) {
@@ -237,6 +340,8 @@ BVH BVH::build(const std::vector<Bounds>& bounds, int max_per_node, PartitionStr
     const int small = 16384; // primitives below which a subtree is one thread's task
     if (strat == BVH_SAH && max_per_node == 1 && n_threads > 1 && (int)bounds.size() > 2 * small)
         b.run_threaded(n_threads, small);
+    else if (n_threads > 1 && (int)bounds.size() > 2 * small)
+        b.run_threaded_general(n_threads, small);
     else
         b.run();
     out.nodes = std::move(b.nodes_);

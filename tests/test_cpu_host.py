@@ -71,6 +71,22 @@ def test_threaded_sah_build_is_bit_identical(rta, orc, monkeypatch):
     assert sn.tobytes() == hn.tobytes() and np.array_equal(si, hi)
 
 
+@pytest.mark.parametrize("leaf,strat", [(2, 1), (4, 1), (3, 0), (1, 0)])
+def test_threaded_build_other_leaf_sizes_is_bit_identical(rta, orc, monkeypatch, leaf, strat):
+    """Larger leaves and BVH_MIDDLE have no subtree size known in advance: subtrees are built into private arrays and
+    renumbered in the recursion's order afterwards.  Same bytes as the oracle's recursion and as the one-thread build."""
+    n = 40_000
+    b = _random_bounds(n, 7 + leaf, False)
+    b[2000:2300] = b[2000]
+    monkeypatch.setenv("RT_BVH_THREADS", "5")
+    hn, hi = rta.bvh_build(b, leaf, strat)
+    on, oi = orc.bvh_build(b, leaf, strat)
+    assert hn.tobytes() == on.tobytes() and np.array_equal(hi, oi)
+    monkeypatch.setenv("RT_BVH_THREADS", "1")
+    sn, si = rta.bvh_build(b, leaf, strat)
+    assert sn.tobytes() == hn.tobytes() and np.array_equal(si, hi)
+
+
 def test_tri_bounds_and_mesh_build(rta, orc):
     sc = scenes.quad_room(rta)
     sc.build()
