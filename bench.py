@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-per-leaf", type=int, default=None, help="max_per_node of BVH::build (1 = what the reference's TriangleMesh passes); "
-                    "default: 2 for cornellbox, 1 for the other flat workloads")
+                    "default: 2, random1m 1 (instanced5m's mesh is a TriangleMesh: always 1)")
     ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m", "instanced5m", "instanced5m_flat"], default="cornellbox",
                     help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow "
                          "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces; "
@@ -116,9 +116,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    probe_leaf = args.max_per_leaf is not None and args.workload != "cornellbox"  # another tree than the workload's visit statistics describe
-    if args.max_per_leaf is None:
-        args.max_per_leaf = 2 if args.workload == "cornellbox" else 1
+    if args.max_per_leaf is None:  # measured per workload: random1m walks 3 % slower with two triangles per leaf, the others 5-8 % faster
+        args.max_per_leaf = 1 if args.workload == "random1m" else 2
     # ---- scene: load, build the BVH on the host, flatten, upload once
     t0 = time.time()
     depth = DEPTH
@@ -130,11 +129,7 @@ def main():
         # leaf walk 5 % faster with identical hits (6.75 -> 7.07 Grays/s; 3: 6.65, 4: 6.42, 8: 5.25).
         sc.build(max_per_leaf=args.max_per_leaf)
         cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
-        label = f"cornellbox.glb, BVH::build(bounds, {args.max_per_leaf}, BVH_SAH),"
-        if args.max_per_leaf == 2:
-            visits_json = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8_leaf2.json")
-        elif args.max_per_leaf != 1:
-            visits_json = ""  # no visit statistics for this tree: no roofline
+        label = "cornellbox.glb"
     elif args.workload == "random1m":  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
         sc = scenes.random_triangles(rta, 1_000_000)
         sc.build(max_per_leaf=args.max_per_leaf)  # the reference's SAH builder (multi-threaded, same output)
@@ -162,6 +157,12 @@ def main():
         sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
         visits_json = os.path.join(ROOT, "profiles", "visits_spheres10m_4k_d8.json")
         label = "10 000 tessellated spheres (9.6M triangles, seed 1234), rectangle light + uniform environment"
+    if args.workload != "instanced5m":
+        label = f"{label}, BVH::build(bounds, {args.max_per_leaf}, BVH_SAH),"
+        if args.max_per_leaf == 2:  # visit statistics are per tree (tools/measure_visits.py <workload>_leaf2)
+            visits_json = visits_json[:-5] + "_leaf2.json"
+        elif args.max_per_leaf != 1:
+            visits_json = ""  # no visit statistics for this tree: no roofline
     t_build = time.time() - t0
     sc.upload(local_rank)
 
@@ -242,7 +243,7 @@ def main():
             },
         }
         # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
-        visits = json.load(open(visits_json)) if os.path.exists(visits_json) and not probe_leaf else None
+        visits = json.load(open(visits_json)) if os.path.exists(visits_json) else None
         kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"  # (k_closest2 / k_shadow2 on a two-level scene)
         if visits and max(stats["ms_closest"], stats["ms_shadow"]) > 0:
             v = visits["closest" if kern == "k_closest" else "shadow"]

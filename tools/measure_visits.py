@@ -18,19 +18,22 @@ import raytracing_amd as rta  # noqa: E402
 import scenes  # noqa: E402
 
 WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "cornellbox"
-if WORKLOAD in ("cornellbox", "cornellbox_leaf2"):  # _leaf2: BVH::build(bounds, 2, BVH_SAH) — the tree bench.py walks by default
+per_leaf = 2 if WORKLOAD.endswith("_leaf2") else 1  # <workload>_leaf2: BVH::build(bounds, 2, BVH_SAH) — the tree bench.py walks by default
+if per_leaf == 2:
+    WORKLOAD = WORKLOAD[: -len("_leaf2")]
+    assert WORKLOAD != "instanced5m", "the two-level scene's meshes are built by TriangleMesh (single-triangle leaves)"
+if WORKLOAD == "cornellbox":
     W, H, SPP, DEPTH = 480, 270, 8, 8
-    per_leaf = 2 if WORKLOAD.endswith("leaf2") else 1
     sc = scenes.cornellbox(rta)
     sc.build(max_per_leaf=per_leaf)
     cam = scenes.cornell_camera(rta, sc, W, H)
     label = f"cornellbox.glb GGX+Beckmann, depth {DEPTH}, camera of the file, BVH::build(bounds, {per_leaf}, BVH_SAH)"
-    name = "visits_cornellbox_1080p_d8.json" if per_leaf == 1 else "visits_cornellbox_1080p_d8_leaf2.json"
+    name = "visits_cornellbox_1080p_d8.json"
 elif WORKLOAD == "spheres10m":  # BASELINE config 4 geometry: 9.6 M triangles (the SAH build takes about a minute on 8 cores)
     W, H, SPP, DEPTH = 480, 270, 1, 8
     import numpy as np
     sc = scenes.sphere_field(rta)
-    sc.build()
+    sc.build(max_per_leaf=per_leaf)
     sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
     cam = scenes.random_triangles_camera(rta, W, H)
     label = "10 000 tessellated spheres (9.6 M triangles, seed 1234), rectangle light + uniform environment, depth 8"
@@ -45,17 +48,21 @@ elif WORKLOAD == "instanced5m":  # BASELINE config 5 as a two-level scene (an in
 elif WORKLOAD == "instanced5m_flat":  # the same surfaces flattened into one 5 M-triangle mesh (the SAH build takes about a minute on 8 cores)
     W, H, SPP, DEPTH = 480, 270, 2, 8
     sc = scenes.legacy_instanced_flat(rta)
-    sc.build()
+    sc.build(max_per_leaf=per_leaf)
     cam = scenes.legacy_instanced_camera(rta, W, H)
     label = "room + one 99 856-triangle mesh x 50 flattened into one mesh, depth 8"
     name = "visits_instanced5m_flat_1080p_d8.json"
 else:  # BASELINE config 3: 1 000 000 random triangles, primary + shadow rays only (depth 1); the SAH build takes ~40 s
     W, H, SPP, DEPTH = 480, 270, 2, 1
     sc = scenes.random_triangles(rta, 1_000_000)
-    sc.build()
+    sc.build(max_per_leaf=per_leaf)
     cam = scenes.random_triangles_camera(rta, W, H)
     label = "1 000 000 random triangles in the unit box (seed 1234), one rectangle light, depth 1"
     name = "visits_random1m_1080p_d1.json"
+if per_leaf == 2:
+    name = name[:-5] + "_leaf2.json"
+    if WORKLOAD != "cornellbox":
+        label += ", BVH::build(bounds, 2, BVH_SAH)"
 osc = orc.two_level_scene_from_host(sc) if WORKLOAD == "instanced5m" else orc.scene_from_host(sc)
 orc.lib().orc_count_product_occlusion_walk(1)  # shadow-ray visits of the walk the kernels run (boxes beyond tmax skipped)
 _, c = orc.render(osc, cam, W, H, SPP, DEPTH, seed=1, spp_total=1024)
