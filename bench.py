@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-per-leaf", type=int, default=None, help="max_per_node of BVH::build (1 = what the reference's TriangleMesh passes); "
-                    "default: 2, random1m 1 (instanced5m's mesh is a TriangleMesh: always 1)")
+                    "default: 2, random1m 1 (instanced5m: TriangleMesh(mesh, max_per_node))")
     ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m", "instanced5m", "instanced5m_flat"], default="cornellbox",
                     help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow "
                          "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces; "
@@ -138,7 +138,7 @@ def main():
         visits_json = os.path.join(ROOT, "profiles", "visits_random1m_1080p_d1.json")
         label = "1M random triangles (seed 1234), one rectangle light"
     elif args.workload == "instanced5m":  # BASELINE configs[4], kept two-level: TLAS + ONE mesh BVH + per-instance ray transforms
-        sc = scenes.legacy_instanced(rta)
+        sc = scenes.legacy_instanced(rta, max_per_leaf=args.max_per_leaf)  # TriangleMesh(mesh, max_per_node); the reference's constant is 1
         sc.build()
         cam = scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
         visits_json = os.path.join(ROOT, "profiles", "visits_instanced5m_1080p_d8.json")
@@ -157,12 +157,11 @@ def main():
         sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
         visits_json = os.path.join(ROOT, "profiles", "visits_spheres10m_4k_d8.json")
         label = "10 000 tessellated spheres (9.6M triangles, seed 1234), rectangle light + uniform environment"
-    if args.workload != "instanced5m":
-        label = f"{label}, BVH::build(bounds, {args.max_per_leaf}, BVH_SAH),"
-        if args.max_per_leaf == 2:  # visit statistics are per tree (tools/measure_visits.py <workload>_leaf2)
-            visits_json = visits_json[:-5] + "_leaf2.json"
-        elif args.max_per_leaf != 1:
-            visits_json = ""  # no visit statistics for this tree: no roofline
+    label = f"{label}, BVH::build(bounds, {args.max_per_leaf}, BVH_SAH),"
+    if args.max_per_leaf == 2:  # visit statistics are per tree (tools/measure_visits.py <workload>_leaf2)
+        visits_json = visits_json[:-5] + "_leaf2.json"
+    elif args.max_per_leaf != 1:
+        visits_json = ""  # no visit statistics for this tree: no roofline
     t_build = time.time() - t0
     sc.upload(local_rank)
 

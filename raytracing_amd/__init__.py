@@ -135,7 +135,7 @@ def load_libraries():
     host.rth_camera_ray.argtypes = [vp, f32, i32, i32, f32, f32, vp]
     host.rth_render_image.argtypes = [vp, vp, f32, i32, i32, i32, i32, C.c_uint32, C.c_char_p, vp, vp, C.POINTER(RtStats)]
     host.rth_scene_closest_hit.argtypes = [vp, vp, vp, vp, vp, vp]
-    host.rth_scene_new_triangle_mesh.argtypes = [vp, vp, i64, vp, i64]
+    host.rth_scene_new_triangle_mesh.argtypes = [vp, vp, i64, vp, i64, i32]
     host.rth_scene_new_triangle_mesh.restype = i32
     host.rth_scene_add_mesh_instance.argtypes = [vp, i32, i32, vp]
     host.rth_scene_add_mesh_instance.restype = i32
@@ -263,14 +263,15 @@ class Scene:
 
     # ---- legacy two-level scenes: Scene::instances (Object.h:364-423).  A scene with instances is two-level: build()
     # builds the TLAS over their world bounds (Scene.cpp:6-15) and the merged mesh is unused.
-    def new_triangle_mesh(self, verts, tris):
-        """TriangleMesh(mesh): builds the mesh's own BVH once; returns a handle for add_mesh_instance."""
+    def new_triangle_mesh(self, verts, tris, max_per_leaf=1):
+        """TriangleMesh(mesh): builds the mesh's own BVH once (max_per_leaf = BVH::build's max_per_node; the reference
+        passes 1, Object.cpp:21); returns a handle for add_mesh_instance."""
         verts = np.ascontiguousarray(verts, dtype=VERTEX)
         tris = np.ascontiguousarray(tris, dtype=TRIANGLE)
         if len(tris) == 0 or int(tris["idx"].max()) >= len(verts):
             raise ValueError("empty mesh or triangle index out of range")
         self.n_triangle_meshes += 1
-        return int(self._host.rth_scene_new_triangle_mesh(self._h, _ptr(verts), len(verts), _ptr(tris), len(tris)))
+        return int(self._host.rth_scene_new_triangle_mesh(self._h, _ptr(verts), len(verts), _ptr(tris), len(tris), int(max_per_leaf)))
 
     def add_mesh_instance(self, mesh, material, transform16):
         i = self._host.rth_scene_add_mesh_instance(self._h, int(mesh), int(material), _ptr(_f32(transform16, 16)))

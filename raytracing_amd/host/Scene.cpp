@@ -189,12 +189,12 @@ void Cylinder::describe(rt_instance* o) const {
     o->p[1] = ymin;
     o->p[2] = ymax;
 }
-TriangleMesh::TriangleMesh(const Mesh* mesh_) : mesh(mesh_) { // Object.cpp:11-29
+TriangleMesh::TriangleMesh(const Mesh* mesh_, int max_per_node) : mesh(mesh_) { // Object.cpp:11-29
     std::vector<Bounds> b;
     b.reserve(mesh->triangles.size());
     for (const MeshTriangle& t : mesh->triangles)
         b.push_back(tri_bounds(mesh->verts[t.indicies[0]].position, mesh->verts[t.indicies[1]].position, mesh->verts[t.indicies[2]].position));
-    bvh = BVH::build(b, 1, BVH_SAH);
+    bvh = BVH::build(b, max_per_node < 1 ? 1 : max_per_node, BVH_SAH);
     mesh_bounds = bvh.nodes[0].aabb;
 }
 void TriangleMesh::describe(rt_instance* o) const { o->geometry = RT_GEO_MESH; } // blas_root: Scene::flatten_two_level

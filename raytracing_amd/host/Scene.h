@@ -123,7 +123,8 @@ public:
 };
 class TriangleMesh : public Geometry { // Object.h:266-362, Object.cpp:11-29: borrows the mesh, owns its BVH
 public:
-    explicit TriangleMesh(const Mesh* mesh);
+    // max_per_node: BVH::build's parameter; the reference passes 1 (Object.cpp:21)
+    explicit TriangleMesh(const Mesh* mesh, int max_per_node = 1);
     Bounds object_bounds() const override { return mesh_bounds; }
     void describe(rt_instance* out) const override;
     const Mesh* mesh;

@@ -47,14 +47,14 @@ void rth_scene_free(rth_scene* s) {
 // ---- legacy two-level scenes: Scene::instances (Object.h:364-423) ------------------------------------------------
 // TriangleMesh(import_mesh(...)) of the scene scripts (main.cpp:456,647): builds the mesh's own BVH once; returns a
 // handle to place it with rth_scene_add_mesh_instance any number of times.
-int32_t rth_scene_new_triangle_mesh(rth_scene* s, const void* verts, int64_t n_verts, const void* tris, int64_t n_tris) {
+int32_t rth_scene_new_triangle_mesh(rth_scene* s, const void* verts, int64_t n_verts, const void* tris, int64_t n_tris, int32_t max_per_leaf) {
     Mesh* m = new Mesh;
     const Vertex* v = (const Vertex*)verts;
     const MeshTriangle* t = (const MeshTriangle*)tris;
     m->verts.assign(v, v + n_verts);
     m->triangles.assign(t, t + n_tris);
     s->meshes.push_back(m);
-    s->mesh_geometry.push_back(new TriangleMesh(m));
+    s->mesh_geometry.push_back(new TriangleMesh(m, max_per_leaf));
     s->mesh_placed.push_back(false);
     return (int32_t)s->mesh_geometry.size() - 1;
 }

@@ -209,7 +209,7 @@ def _trs(translate=(0, 0, 0), scale=1.0, rot_y_deg=0.0, rot_x_deg=0.0):
     return m.T.reshape(-1).astype(np.float32)
 
 
-def legacy_two_level(rta, env=0.05, light=True, mesh_lat=12, mesh_lon=24, mesh_copies=3, extra_spheres=0, seed=5):
+def legacy_two_level(rta, env=0.05, light=True, mesh_lat=12, mesh_lon=24, mesh_copies=3, extra_spheres=0, seed=5, mesh_max_per_leaf=1):
     """A scene of the legacy design, in the shape of the reference's BallTestScene / Conference scripts
     (main.cpp:725-833): Scene::instances of Rectangle, Sphere, Box, Cylinder, Disk and one TriangleMesh placed several
     times with scale + rotation + translation, a Rectangle light in both `instances` and `lights`, under a TLAS."""
@@ -232,7 +232,7 @@ def legacy_two_level(rta, env=0.05, light=True, mesh_lat=12, mesh_lon=24, mesh_c
     if mesh_copies:
         v, t = uv_sphere(rta, mesh_lat, mesh_lon)
         v["pos"][:, 1] *= 1.6  # an ellipsoid, so rotations matter
-        mesh = sc.new_triangle_mesh(v, t)
+        mesh = sc.new_triangle_mesh(v, t, mesh_max_per_leaf)
         rng = np.random.default_rng(seed)
         for k in range(mesh_copies):
             m = _trs((-0.35 + 0.1 * k, 0.2 + 0.12 * k, -0.6 + 0.55 * k), scale=0.07 + 0.02 * k, rot_y_deg=float(rng.uniform(0, 360)),
@@ -251,7 +251,7 @@ def legacy_camera(rta, width, height):
     return rta.camera(rta.look_at((-1.4, 0.7, 0.0), (0.0, 0.2, 0.0), (0, 1, 0)), 45.0, width, height)
 
 
-def legacy_instanced(rta, n_lat=159, n_lon=316, copies=50, seed=99, env=0.05):
+def legacy_instanced(rta, n_lat=159, n_lon=316, copies=50, seed=99, env=0.05, max_per_leaf=1):
     """BASELINE config 5 as the legacy two-level design holds it: ONE mesh (a UV sphere of 2 n_lon (n_lat - 1) triangles:
     99 856 by default) placed `copies` times by Instance transforms — one BVH of 100k triangles in memory instead of the
     5 M flattened ones — inside a room of five Rectangle instances, under a Rectangle light."""
@@ -270,7 +270,7 @@ def legacy_instanced(rta, n_lat=159, n_lon=316, copies=50, seed=99, env=0.05):
     sc.add_primitive_instance(R, (-1, 0, 0, 3.2, 3.2), green, _trs((1.6, 1.6, 0)))
     sc.add_primitive_instance(R, (0, -1, 0, 0.8, 0.8), emit, _trs((0, 3.19, 0)), light=True)
     v, t = uv_sphere(rta, n_lat, n_lon)
-    mesh = sc.new_triangle_mesh(v, t)
+    mesh = sc.new_triangle_mesh(v, t, max_per_leaf)
     for k, m in enumerate(instance_transforms(copies, seed, scale=(0.12, 0.3))):
         sc.add_mesh_instance(mesh, [ggx, metal, white][k % 3], m)
     if env:

@@ -178,6 +178,28 @@ def test_config5_two_level_scale(rta, orc, gpu):
     assert st["paths"] == oc["paths"]
 
 
+def test_mesh_with_two_triangles_per_leaf(rta, orc, gpu):
+    """TriangleMesh(mesh, 2): BVH::build's max_per_node above the reference's 1 (Object.cpp:21).  Bit-exact against the
+    oracle walking the same tree, and the same hits as the single-triangle-leaf tree finds."""
+    out = []
+    for leaf in (1, 2):
+        sc = scenes.legacy_two_level(rta, mesh_lat=24, mesh_lon=48, mesh_copies=5, mesh_max_per_leaf=leaf)
+        sc.build()
+        sc.upload(gpu)
+        w, h = 96, 64
+        rays = orc.camera_rays(scenes.legacy_camera(rta, w, h), w, h, 2, 8)
+        hits, idx = sc.trace_closest_indexed(rays)
+        osc = orc.two_level_scene_from_host(sc)
+        ref, ridx, _, _ = orc.closest_hit2(osc, rays)
+        assert np.array_equal(idx, ridx) and hits.tobytes() == ref.tobytes()
+        tmax = (np.where(np.isfinite(ref["t"]), ref["t"], 1.0) * 1.01).astype(np.float32)
+        assert np.array_equal(sc.trace_any(rays, tmax), orc.any_hit2(osc, rays, tmax))
+        nodes = sc.mesh_array(0, 2)
+        assert nodes["count"].max() == leaf
+        out.append((hits["t"].copy(), idx.copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_cli_balltest_scene(rta, gpu, tmp_path, capfd):
     """python -m raytracing_amd balltest: the reference's BallTestScene as a two-level scene, through Renderer::render_image."""
     from raytracing_amd.__main__ import main

@@ -21,7 +21,6 @@ WORKLOAD = sys.argv[1] if len(sys.argv) > 1 else "cornellbox"
 per_leaf = 2 if WORKLOAD.endswith("_leaf2") else 1  # <workload>_leaf2: BVH::build(bounds, 2, BVH_SAH) — the tree bench.py walks by default
 if per_leaf == 2:
     WORKLOAD = WORKLOAD[: -len("_leaf2")]
-    assert WORKLOAD != "instanced5m", "the two-level scene's meshes are built by TriangleMesh (single-triangle leaves)"
 if WORKLOAD == "cornellbox":
     W, H, SPP, DEPTH = 480, 270, 8, 8
     sc = scenes.cornellbox(rta)
@@ -40,7 +39,7 @@ elif WORKLOAD == "spheres10m":  # BASELINE config 4 geometry: 9.6 M triangles (t
     name = "visits_spheres10m_4k_d8.json"
 elif WORKLOAD == "instanced5m":  # BASELINE config 5 as a two-level scene (an instance test counts as 3 inner visits: its 192-byte record)
     W, H, SPP, DEPTH = 480, 270, 2, 8
-    sc = scenes.legacy_instanced(rta)
+    sc = scenes.legacy_instanced(rta, max_per_leaf=per_leaf)  # TriangleMesh(mesh, per_leaf)
     sc.build()
     cam = scenes.legacy_instanced_camera(rta, W, H)
     label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), depth 8"
