@@ -228,11 +228,14 @@ struct MeshHit {
     float u = 0, v = 0;
 };
 
+bool g_count_product_occlusion_walk = false; // orc_count_product_occlusion_walk(): visit statistics only
+
 // TriangleMesh::intersect traversal, Object.h:273-344.  any = stop at the first
 // accepted hit (boolean use of trace_scene, main.cpp:250,281).
-// cull_tmax is NOT the reference: it restates the one place where the product's occlusion walk leaves the reference's
-// procedure (boxes entered beyond the segment's end are skipped) and exists only so that
-// tools/measure_visits.py can count the nodes THAT walk visits.  Every parity check runs with cull_tmax = false.
+// cull_tmax is NOT the reference: it restates the one place where the product's walks leave the reference's procedure
+// (boxes entered beyond the end of the segment handed in are skipped: occlusion rays, and a mesh instance entered with
+// the closest hit of other instances as tmax) and exists only so that tools/measure_visits.py can count
+// the nodes THOSE walks visit.  Every parity check runs with cull_tmax = false.
 inline bool mesh_traverse(const orc_mesh* s, const V3& o, const V3& d, float tmin, float tmax, bool any, MeshHit& out,
                           orc_visits* vis, bool cull_tmax = false) {
     int stack[64];
@@ -275,7 +278,7 @@ inline bool mesh_traverse(const orc_mesh* s, const V3& o, const V3& d, float tmi
         bool rh = slab(R->bmin, R->bmax, o, d, rd);
         lh = lh && ld < t;
         rh = rh && rd < t;
-        if (any && cull_tmax) {
+        if (cull_tmax) {
             lh = lh && ld < segment_end;
             rh = rh && rd < segment_end;
         }
@@ -437,7 +440,7 @@ inline bool cylinder_intersect(const float* p, const V3& o, const V3& d, float t
 // TriangleMesh::intersect (Object.h:273-357): the walk, then the interpolated normal
 inline bool trimesh_intersect(const orc_mesh* m, const V3& o, const V3& d, float tmin, float tmax, GeoHit* si, orc_visits* vis) {
     MeshHit h;
-    if (!mesh_traverse(m, o, d, tmin, tmax, false, h, vis)) return false;
+    if (!mesh_traverse(m, o, d, tmin, tmax, false, h, vis, g_count_product_occlusion_walk)) return false;
     const orc_triangle& tri = m->tris[h.tri];
     si->point = o + d * h.t;
     float bw = 1 - h.u - h.v; // bary = (bary_temp.z, .x, .y): weights of corners 0, 1, 2 (Object.h:317,351-353)
@@ -1301,7 +1304,6 @@ struct Ctx {
     uint64_t rays_closest = 0, rays_shadow = 0, inner = 0, leaf = 0, s_inner = 0, s_leaf = 0;
 };
 
-bool g_count_product_occlusion_walk = false; // orc_count_product_occlusion_walk(): visit statistics only
 
 bool occluded(Ctx& c, const V3& o, const V3& d, float tmin, float tmax) {
     c.rays_shadow++;

@@ -831,7 +831,10 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
                 bool lh, rh;
                 if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
                 else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
-                const float cull = ANY ? tcull : (in_inst >= 0 ? t_local : t_best);
+                // inside a mesh the reference culls by the mesh's own closest hit only (t_local).  Boxes entered beyond
+                // the closest hit over ALL instances hold no triangle that can be accepted (t <= t_best, Object.h:312):
+                // they are skipped too, with occlusion_queue's margin against the rounding of the box test — same hits.
+                const float cull = ANY ? tcull : (in_inst >= 0 ? fminf(t_local, t_best * 1.0001f + 0.000001f) : t_best);
                 lh = lh && ld < cull;
                 rh = rh && rd < cull;
                 const bool left_first = ld < rd;
