@@ -1191,7 +1191,11 @@ RT_DEV V3 matte_albedo(const rt_material& m, const Surf& si) {
     const float grid = m.s[0];
     if (grid == 0.f) return V3(m.c0);
     const bool odd = ((double)modulo_f(si.u, grid) < (double)grid * 0.5) ^ ((double)modulo_f(si.v, grid) < (double)grid * 0.5);
-    return odd ? V3(m.c1) : V3(m.c0);
+    // selected by VALUE: `odd ? V3(m.c1) : V3(m.c0)` becomes a select of two addresses, which keeps the whole record in
+    // scratch memory — its type field with it, so the per-type kernels stop folding their switch (two-level shading
+    // kernels carried every material's code: 246 VGPRs, two waves per SIMD)
+    const float e0 = m.c0[0], e1 = m.c0[1], e2 = m.c0[2], o0 = m.c1[0], o1 = m.c1[1], o2 = m.c1[2];
+    return V3(odd ? o0 : e0, odd ? o1 : e1, odd ? o2 : e2);
 }
 
 // Material::Eval

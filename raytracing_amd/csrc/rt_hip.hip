@@ -488,8 +488,11 @@ struct ShadeOrder { // the shading kernels of a bounce in launch order
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 1
 #endif
+#ifndef RT_SHADE_WAVES_TL
+#define RT_SHADE_WAVES_TL 1
+#endif
 template <int KEY, bool TL>
-__global__ __launch_bounds__(RT_BLOCK, RT_SHADE_WAVES) void k_shade_t(SceneView sc_in, Wave w, PassParams pp, ShadeOrder order, int bounce, int last_bounce) {
+__global__ __launch_bounds__(RT_BLOCK, TL ? RT_SHADE_WAVES_TL : RT_SHADE_WAVES) void k_shade_t(SceneView sc_in, Wave w, PassParams pp, ShadeOrder order, int bounce, int last_bounce) {
     // The sampling CDFs are walked by dependent binary searches (7 + 10 steps on cornellbox) and the environment is read
     // with four bilinear taps: from LDS when all the tables fit (wave-uniform choice between two instantiations).
     __shared__ float s_env_cdf[RT_LDS_ENV];
