@@ -251,8 +251,12 @@ def main():
             launches = stats["launches_closest"] if kern == "k_closest" else stats["launches_shadow"]
             gbps = n_rays * v["bytes_per_ray"] / (ms * 1e-3) / 1e9
             traffic = None
-            if os.path.exists(PMC_JSON) and args.workload == "cornellbox" and args.max_per_leaf == 2:
-                pmc = json.load(open(PMC_JSON)).get(kern, {})
+            # HBM bytes per launch from the PMC passes of tools/profile_pmc.sh over this workload and tree (two-level kernels
+            # are listed as k_closest2 / k_shadow2)
+            pmc_json = PMC_JSON if args.workload == "cornellbox" else os.path.join(ROOT, "profiles", f"r01_pmc_summary_{args.workload}.json")
+            if os.path.exists(pmc_json) and args.max_per_leaf == (1 if args.workload == "random1m" else 2):
+                pmc = json.load(open(pmc_json))
+                pmc = pmc.get(kern + "2", {}) if args.workload == "instanced5m" else pmc.get(kern, {})
                 if pmc.get("dispatches") and "hbm_read_bytes_corrected" in pmc and "hbm_write_bytes" in pmc:
                     traffic = (pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]) / pmc["dispatches"]
             out["roofline"] = {
