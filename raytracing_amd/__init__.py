@@ -133,6 +133,8 @@ def load_libraries():
     host.rth_look_at.argtypes = [vp, vp, vp, vp]
     host.rth_camera_init.argtypes = [vp, f32, i32, i32, i32, f32, C.POINTER(RtCamera)]
     host.rth_camera_ray.argtypes = [vp, f32, i32, i32, f32, f32, vp]
+    host.rth_write_image.argtypes = [C.c_char_p, i32, i32, vp]
+    host.rth_write_image.restype = i32
     host.rth_render_image.argtypes = [vp, vp, f32, i32, i32, i32, i32, C.c_uint32, C.c_char_p, vp, vp, C.POINTER(RtStats)]
     host.rth_scene_closest_hit.argtypes = [vp, vp, vp, vp, vp, vp]
     host.rth_scene_new_triangle_mesh.argtypes = [vp, vp, i64, vp, i64, i32]
@@ -174,6 +176,17 @@ def device_count():
 def last_error():
     hip, _ = load_libraries()
     return hip.rt_last_error().decode()
+
+
+def write_image(path, rgb):
+    """The Renderer's output writer (main.cpp:1015) on its own: rgb = (h, w, 3) uint8, row 0 = top; `.png` by
+    extension (stored deflate blocks), anything else is written as a 24-bit BMP."""
+    _, host = load_libraries()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    if rgb.ndim != 3 or rgb.shape[2] != 3 or rgb.shape[0] < 1 or rgb.shape[1] < 1:
+        raise ValueError("write_image: rgb must be (h, w, 3) uint8")
+    if not host.rth_write_image(os.fsencode(path), rgb.shape[1], rgb.shape[0], _ptr(rgb)):
+        raise OSError(f"write_image: cannot write {path}")
 
 
 def look_at(eye, at, up):

@@ -40,7 +40,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m raytracing_amd", description=__doc__)
     ap.add_argument("scene", help=".glb / .gltf file, or `balltest`: the reference's BallTestScene (main.cpp:725-781), a legacy two-level "
                                   "scene of Rectangle and Sphere instances under a TLAS")
-    ap.add_argument("-o", "--out", default="output.bmp", help="BMP to write (main.cpp:29 OUTPUT_NAME)")
+    ap.add_argument("-o", "--out", default="output.bmp", help="image to write (main.cpp:29 OUTPUT_NAME): .png by extension, else BMP")
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--height", type=int, default=512)
     ap.add_argument("--spp", type=int, default=64, help="samples per pixel (main.cpp:22 SAMPLES_PER_PIXEL)")

@@ -678,7 +678,7 @@ void Renderer::render_image(const Camera& cam, const Scene& scene, const Options
         return;
     }
     std::printf("\nDONE, seconds elapsed: %g\n", last_stats.ms_total / 1000.0);
-    if (write_output && write_bmp(options.output_name, width, height, final_buffer.data()))
+    if (write_output && write_image(options.output_name, width, height, final_buffer.data()))
         std::printf("Output written: %s\n", options.output_name.c_str());
 }
 
@@ -711,6 +711,88 @@ bool write_bmp(const std::string& path, int w, int h, const uint8_t* rgb) {
     }
     std::fclose(fp);
     return true;
+}
+
+// PNG with the image data in stored deflate blocks: no compressor needed, every decoder reads it.  Rows top-down, one
+// filter byte (0 = none) before each.
+bool write_png(const std::string& path, int w, int h, const uint8_t* rgb) {
+    if (w <= 0 || h <= 0) return false;
+    FILE* fp = std::fopen(path.c_str(), "wb");
+    if (!fp) return false;
+    uint32_t crc_table[256];
+    for (uint32_t n = 0; n < 256; n++) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+        crc_table[n] = c;
+    }
+    auto be32 = [](uint8_t* p, uint32_t v) {
+        p[0] = (uint8_t)(v >> 24);
+        p[1] = (uint8_t)(v >> 16);
+        p[2] = (uint8_t)(v >> 8);
+        p[3] = (uint8_t)v;
+    };
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& data) {
+        uint8_t head[8];
+        be32(head, (uint32_t)data.size());
+        std::memcpy(head + 4, type, 4);
+        uint32_t c = 0xFFFFFFFFu;
+        for (int i = 4; i < 8; i++) c = crc_table[(c ^ head[i]) & 0xFFu] ^ (c >> 8);
+        for (uint8_t b : data) c = crc_table[(c ^ b) & 0xFFu] ^ (c >> 8);
+        uint8_t tail[4];
+        be32(tail, c ^ 0xFFFFFFFFu);
+        std::fwrite(head, 1, 8, fp);
+        if (!data.empty()) std::fwrite(data.data(), 1, data.size(), fp);
+        std::fwrite(tail, 1, 4, fp);
+    };
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::fwrite(sig, 1, 8, fp);
+    std::vector<uint8_t> ihdr(13, 0);
+    be32(&ihdr[0], (uint32_t)w);
+    be32(&ihdr[4], (uint32_t)h);
+    ihdr[8] = 8; // bits per channel
+    ihdr[9] = 2; // truecolour
+    chunk("IHDR", ihdr);
+    const size_t row = (size_t)w * 3 + 1, raw = row * (size_t)h;
+    std::vector<uint8_t> z;
+    z.reserve(raw + raw / 65535 * 5 + 16);
+    z.push_back(0x78); // zlib header: deflate, 32 KiB window, no preset dictionary
+    z.push_back(0x01);
+    uint32_t a = 1, b = 0; // Adler-32 of the raw stream
+    std::vector<uint8_t> line(row, 0);
+    std::vector<uint8_t> stream;
+    stream.reserve(raw);
+    for (int y = 0; y < h; y++) {
+        std::memcpy(&line[1], rgb + (size_t)y * w * 3, (size_t)w * 3);
+        stream.insert(stream.end(), line.begin(), line.end());
+    }
+    for (uint8_t v : stream) {
+        a = (a + v) % 65521u;
+        b = (b + a) % 65521u;
+    }
+    for (size_t at = 0; at < raw;) {
+        const size_t n = std::min<size_t>(65535, raw - at);
+        z.push_back(at + n == raw ? 1 : 0); // BFINAL, BTYPE = 00 (stored)
+        z.push_back((uint8_t)(n & 0xFF));
+        z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF));
+        z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), stream.begin() + at, stream.begin() + at + n);
+        at += n;
+    }
+    uint8_t adler[4];
+    be32(adler, (b << 16) | a);
+    z.insert(z.end(), adler, adler + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    const bool ok = !std::ferror(fp);
+    std::fclose(fp);
+    return ok;
+}
+
+bool write_image(const std::string& path, int w, int h, const uint8_t* rgb) {
+    std::string ext = path.size() >= 4 ? path.substr(path.size() - 4) : "";
+    for (char& c : ext) c = (char)std::tolower((unsigned char)c);
+    return ext == ".png" ? write_png(path, w, h, rgb) : write_bmp(path, w, h, rgb);
 }
 
 // -------------------------------------------------------------- materials

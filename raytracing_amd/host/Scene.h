@@ -277,5 +277,7 @@ private:
 };
 
 bool write_bmp(const std::string& path, int w, int h, const uint8_t* rgb);
+bool write_png(const std::string& path, int w, int h, const uint8_t* rgb); // 8-bit RGB, stored (uncompressed) deflate blocks
+bool write_image(const std::string& path, int w, int h, const uint8_t* rgb); // by extension: .png, else BMP (main.cpp:1015 writes BMP)
 
 } // namespace rt

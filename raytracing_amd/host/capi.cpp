@@ -291,6 +291,9 @@ void rth_camera_ray(const float* view16, float fov, int32_t w, int32_t h, float 
     out->d[0] = r.dir.x; out->d[1] = r.dir.y; out->d[2] = r.dir.z;
 }
 
+// the Renderer's output writer on its own (main.cpp:1015): .png by extension, else BMP; rgb = w*h*3 u8, row 0 = top
+int32_t rth_write_image(const char* path, int32_t w, int32_t h, const uint8_t* rgb) { return write_image(path, w, h, rgb) ? 1 : 0; }
+
 // Renderer::render_image (main.cpp:950-1020) through the C++ classes.
 // rgb_out = w*h*3 u8 (row 0 = top), radiance_out (optional) = w*h*3 fp32 sums.
 int32_t rth_render_image(rth_scene* s, const float* view16, float fov, int32_t w, int32_t h, int32_t spp, int32_t max_depth,

@@ -255,3 +255,36 @@ def test_add_instance_flattens_with_the_reference_transform(rta):
     assert np.array_equal(ct["idx"][len(t):], t["idx"] + len(v)) and (ct["material"][len(t):] == 1).all() and (ct["material"][:len(t)] == mid).all()
     c.build()
     assert c.info()["root_ref"] >= 0
+
+
+def test_image_writers_round_trip(rta, tmp_path):
+    """Renderer output (main.cpp:1015 writes a BMP; PNG is this build's addition): both files decode back to the buffer,
+    rows top-down in the buffer.  The PNG is checked chunk by chunk (CRC-32, zlib stream with Adler-32, filter 0)."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(5)
+    for w, h in ((1, 1), (37, 23), (300, 250)):  # 300x250x3 > 65535 bytes: several stored blocks
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        png, bmp = tmp_path / f"o{w}.PNG", tmp_path / f"o{w}.bmp"
+        rta.write_image(str(png), img)
+        rta.write_image(str(bmp), img)
+        data = png.read_bytes()
+        assert data[:8] == b"\x89PNG\r\n\x1a\n"
+        at, chunks = 8, []
+        while at < len(data):
+            n, typ = struct.unpack(">I4s", data[at:at + 8])
+            body = data[at + 8:at + 8 + n]
+            assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(typ + body)
+            chunks.append((typ, body))
+            at += 12 + n
+        assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+        assert struct.unpack(">IIBBBBB", chunks[0][1]) == (w, h, 8, 2, 0, 0, 0)
+        raw = np.frombuffer(zlib.decompress(chunks[1][1]), np.uint8).reshape(h, 1 + 3 * w)
+        assert np.all(raw[:, 0] == 0) and np.array_equal(raw[:, 1:].reshape(h, w, 3), img)
+        b = bmp.read_bytes()
+        assert b[:2] == b"BM" and struct.unpack("<ii", b[18:26]) == (w, h)
+        row = (3 * w + 3) & ~3
+        px = np.frombuffer(b[54:], np.uint8).reshape(h, row)[::-1, :3 * w].reshape(h, w, 3)[:, :, ::-1]
+        assert np.array_equal(px, img)
+    with pytest.raises(OSError):
+        rta.write_image(str(tmp_path / "no_such_dir" / "x.png"), img)

@@ -211,6 +211,17 @@ def test_cli_balltest_scene(rta, gpu, tmp_path, capfd):
     px = np.frombuffer(data[54:], np.uint8)
     assert 20 < px.mean() < 250 and px.std() > 5  # something other than a flat frame
     assert "6 instances" in capfd.readouterr().out
+    # the same frame as a PNG (same seed): identical pixels
+    import struct
+    import zlib
+    png = tmp_path / "balls.png"
+    assert main(["balltest", "-o", str(png), "--width", "96", "--height", "64", "--spp", "8", "--depth", "4", "--env", "0.5"]) == 0
+    p = png.read_bytes()
+    assert p[:8] == b"\x89PNG\r\n\x1a\n" and struct.unpack(">II", p[16:24]) == (96, 64)
+    n = struct.unpack(">I", p[33:37])[0]
+    assert p[37:41] == b"IDAT"
+    rows = np.frombuffer(zlib.decompress(p[41:41 + n]), np.uint8).reshape(64, 1 + 96 * 3)[:, 1:].reshape(64, 96, 3)
+    assert np.array_equal(rows, px.reshape(64, 96, 3)[::-1, :, ::-1])
 
 
 def test_cpp_scene_script_renders(gpu, tmp_path):
