@@ -24,7 +24,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 VISITS_JSON = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
 # rocprofv3 --pmc passes over `bench.py --steps 1` (tools/profile_pmc.sh + tools/summarize_pmc.py), FETCH_SIZE doubled as
 # MI355X_MICROARCH.md prescribes for gfx950; roofline.traffic = HBM bytes per launch of the dominant kernel from it
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary_v9.json")
+PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary_final.json")
 
 
 def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
