@@ -292,6 +292,19 @@ int rt_trace_closest_indexed(rt_scene* scene, const rt_ray* rays, int64_t n, rt_
 int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* tmax, int64_t n,
                  uint8_t* occluded);
 
+/* rt_trace_closest for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same walk, same
+ * kernels and same results as rt_trace_closest, but `rays` and `hits` are DEVICE pointers on the scene's GPU (hits
+ * 16-byte aligned; a miss is tri = -1, t = inf, u = v = 0) and the walk's scratch (two float4 ray streams, shard counters
+ * and fetch cursors, the second hit record of two-level scenes) is a static device array of the library: 24 MiB + 16 KiB
+ * per GPU, held until the process ends.  Limit: n <= RT_NOALLOC_MAX_RAYS, beyond it RT_ERR_LIMIT.  The call makes no
+ * hipMalloc / hipFree and no allocating library call (its error messages are string literals); it runs on the scene's
+ * own stream and returns when the hits are written, so the caller must have finished writing `rays` (synchronise the
+ * producing stream first).  All calls on one GPU share that GPU's array, whatever the scene handle: calls that overlap
+ * on one GPU race and must be serialised by the caller. */
+#define RT_NOALLOC_MAX_RAYS (1 << 19)
+int rt_trace_closest_noalloc(rt_scene* scene, const rt_ray* rays, int64_t n, rt_hit* hits);
+
 /* Replaces the body of Renderer::render_image (main.cpp:950-1005): for every
  * pixel of the tile and every sample of the window, generate the camera ray
  * (Scene.h:61-75), run get_ray_color (main.cpp:325-441) as a wavefront

@@ -82,7 +82,9 @@ class RtError(RuntimeError):
 
 
 HIP_SYMBOLS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_create_instanced", "rt_scene_destroy",
-               "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_render", "rt_resolve", "rt_scene_sync"]
+               "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_resolve",
+               "rt_scene_sync"]
+NOALLOC_MAX_RAYS = 1 << 19
 
 
 def load_libraries():
@@ -103,6 +105,7 @@ def load_libraries():
     hip.rt_trace_closest.argtypes = [vp, vp, i64, vp]
     hip.rt_trace_closest_indexed.argtypes = [vp, vp, i64, vp, vp]
     hip.rt_trace_any.argtypes = [vp, vp, vp, i64, vp]
+    hip.rt_trace_closest_noalloc.argtypes = [vp, vp, i64, vp]
     hip.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtOptions), vp, C.POINTER(RtStats)]
     hip.rt_resolve.argtypes = [vp, vp, i32, i32, i32, f32, vp]
     hip.rt_scene_sync.argtypes = [vp]
@@ -409,6 +412,11 @@ class Scene:
         index = np.zeros(len(rays), np.int32)
         _check(_hip.rt_trace_closest_indexed(self.gpu, _ptr(rays), len(rays), _ptr(hits), _ptr(index)))
         return hits, index
+
+    def trace_closest_noalloc(self, rays_dev, n, hits_dev):
+        """rt_trace_closest_noalloc: device addresses of n rt_ray records in and n rt_hit records out (the caller's memory);
+        the walk's scratch is the library's static device array, nothing is allocated.  Returns the C status code."""
+        return int(_hip.rt_trace_closest_noalloc(self.gpu, C.c_void_p(rays_dev), int(n), C.c_void_p(hits_dev)))
 
     def trace_any(self, rays, tmax):
         rays = np.ascontiguousarray(rays, dtype=RAY)

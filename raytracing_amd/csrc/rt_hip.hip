@@ -22,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -33,8 +34,14 @@ using namespace rtd;
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
+static thread_local const char* g_err_lit = nullptr; // message of a failure reported without touching the heap
 static int fail(int code, const std::string& msg) {
     g_err = msg;
+    g_err_lit = nullptr;
+    return code;
+}
+static int fail_lit(int code, const char* literal) { // for the entry point that must not allocate (std::string may)
+    g_err_lit = literal;
     return code;
 }
 #define HIPCHK(expr)                                                                                         \
@@ -600,8 +607,35 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
     }
 }
 
+// ---- rt_trace_closest_noalloc: the scratch that rt_trace_closest allocates per call — the two
+// float4 ray streams the walk reads, the shard counters and fetch cursors, the second hit record of two-level scenes —
+// lives in ONE file-scope device array.  Every GPU the library runs on holds its own copy at its own address until the
+// process ends; host code never uses the array's name as an address: scene_create resolves it per device with
+// hipGetSymbolAddress and everything below goes through that pointer.
+#define RT_NOALLOC_COUNT_BYTES (2 * RT_SHARDS * RT_CSTRIDE * 4) // counts, then cursors
+#define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_COUNT_BYTES + (size_t)3 * 16 * RT_NOALLOC_MAX_RAYS)
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
+
+// rt_ray[n] (24-byte records, device memory) -> the walk's two float4 streams; the first RT_SHARDS threads also set the
+// shard counters and clear the fetch cursors (the array keeps the previous call's contents).
+__global__ __launch_bounds__(RT_BLOCK) void k_stage_rays(const float* __restrict__ rays, int64_t n, int64_t piece, float4* __restrict__ o,
+                                                         float4* __restrict__ d, uint32_t* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < RT_SHARDS) {
+        const int64_t left = n - i * piece;
+        counts[(size_t)i * RT_CSTRIDE] = (uint32_t)(left < 0 ? 0 : (left > piece ? piece : left));
+        counts[(size_t)(RT_SHARDS + i) * RT_CSTRIDE] = 0u;
+    }
+    if (i >= n) return;
+    const float* r = rays + 6 * i;
+    o[i] = make_float4(r[0], r[1], r[2], INFINITY);
+    d[i] = make_float4(r[3], r[4], r[5], 0.f);
+}
+
 // -------------------------------------------------------------- host side
 #define RT_MAX_SETS 4
+#define RT_MAX_DEVICES 64
+static void* g_scratch_ptr[RT_MAX_DEVICES] = {}; // device address of `scratch` on each GPU (set once per device by scene_create)
 struct rt_scene {
     int device = 0;
     unsigned persistent_blocks = 16;  // resident traversal workgroups: 32 waves per CU, a multiple of RT_SHARDS waves in all
@@ -628,6 +662,7 @@ struct rt_scene {
     int64_t d_sum_n = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
+    unsigned char* scratch_ptr = nullptr; // this GPU's copy of `scratch` (rt_trace_closest_noalloc)
 };
 
 template <typename T>
@@ -713,7 +748,7 @@ static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + RT_BLOCK -
 
 extern "C" {
 
-const char* rt_last_error(void) { return g_err.c_str(); }
+const char* rt_last_error(void) { return g_err_lit ? g_err_lit : g_err.c_str(); }
 
 int rt_device_count(void) {
     int n = 0;
@@ -825,6 +860,17 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
     for (int i = 0; i < RT_MAX_SETS; i++)
         if (hipEventCreateWithFlags(&s->ev_acc[i], hipEventDisableTiming) != hipSuccess) return bail(fail(RT_ERR_HIP, "hipEventCreate failed"));
     if (const char* e = getenv("RT_TUNE_SETS")) s->max_sets = std::max(1, std::min(RT_MAX_SETS, atoi(e)));
+    if (device < RT_MAX_DEVICES) { // this GPU's address of the allocation-free entry point's scratch array (device is current)
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lock(mu);
+        if (!g_scratch_ptr[device]) {
+            void* ptr = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !ptr) return bail(fail(RT_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e)));
+            g_scratch_ptr[device] = ptr;
+        }
+        s->scratch_ptr = (unsigned char*)g_scratch_ptr[device];
+    }
     const rt_bvh_pair* pairs;
     const rt_tri* tris;
     const rt_tri_normals* normals;
@@ -1086,6 +1132,42 @@ int rt_trace_closest_indexed(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit*
 int rt_trace_any(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, uint8_t* occluded) {
     if (!tmax) return fail(RT_ERR_INVALID, "rt_trace_any: tmax is null");
     return trace_common(s, rays, tmax, n, nullptr, occluded);
+}
+
+// rt_trace_closest for callers that cannot allocate: device pointers in and out, the walk's scratch in this GPU's copy of
+// `scratch`.  No hipMalloc / hipFree / allocating library routine on this path (errors are literals, see fail_lit).
+int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit* hits) {
+    if (!s || !rays || !hits || n < 0) return fail_lit(RT_ERR_INVALID, "rt_trace_closest_noalloc: bad argument");
+    if (n > RT_NOALLOC_MAX_RAYS) return fail_lit(RT_ERR_LIMIT, "rt_trace_closest_noalloc: more than 524288 rays in one call (the static scratch holds no more)");
+    if (((uintptr_t)rays & 3u) || ((uintptr_t)hits & 15u)) return fail_lit(RT_ERR_INVALID, "rt_trace_closest_noalloc: rays must be 4-byte and hits 16-byte aligned");
+    if (!s->scratch_ptr) return fail_lit(RT_ERR_HIP, "rt_trace_closest_noalloc: no scratch address for this device");
+    if (n == 0) return RT_OK;
+    if (hipSetDevice(s->device) != hipSuccess) return fail_lit(RT_ERR_HIP, "rt_trace_closest_noalloc: hipSetDevice failed");
+    for (const void* p : {(const void*)rays, (const void*)hits}) { // a host pointer here would be a GPU memory fault in the kernel
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) ||
+            (attr.type == hipMemoryTypeDevice && attr.device != s->device)) {
+            (void)hipGetLastError();
+            return fail_lit(RT_ERR_INVALID, "rt_trace_closest_noalloc: rays and hits must be device memory on the scene's GPU");
+        }
+    }
+    uint32_t* d_count = (uint32_t*)s->scratch_ptr;
+    float4* d_o = (float4*)(s->scratch_ptr + RT_NOALLOC_COUNT_BYTES);
+    float4* d_d = d_o + RT_NOALLOC_MAX_RAYS;
+    float4* d_hit2 = d_d + RT_NOALLOC_MAX_RAYS;
+    const int64_t piece = ((n + RT_SHARDS - 1) / RT_SHARDS + 63) / 64 * 64;
+    const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK;
+    const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
+    hipLaunchKernelGGL(k_stage_rays, dim3(blocks_for(std::max<int64_t>(n, RT_SHARDS))), dim3(RT_BLOCK), 0, s->stream, (const float*)rays, n, piece, d_o, d_d, d_count);
+    if (s->view.inst_q)
+        hipLaunchKernelGGL(k_closest2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                           (uint32_t)RT_SHARDS, (uint32_t)piece, (float4*)hits, d_hit2, 1);
+    else
+        hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                           (uint32_t)RT_SHARDS, (uint32_t)piece, (float4*)hits, 1);
+    if (hipGetLastError() != hipSuccess) return fail_lit(RT_ERR_HIP, "rt_trace_closest_noalloc: kernel launch failed");
+    if (hipStreamSynchronize(s->stream) != hipSuccess) return fail_lit(RT_ERR_HIP, "rt_trace_closest_noalloc: hipStreamSynchronize failed");
+    return RT_OK;
 }
 
 int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* radiance_sum, rt_stats* stats) {
