@@ -1712,6 +1712,24 @@ int32_t orc_material_sample(const orc_material* m, const float* point3, const fl
     return r.used;
 }
 
+// batch forms of the four calls above (tests integrate pdfs by quadrature and histogram samplers: 10^5-10^6 calls)
+void orc_env_eval_batch(const orc_scene* s, const float* dirs3, int64_t n, float* rgb3, float* pdf) {
+    for (int64_t i = 0; i < n; i++) orc_env_eval(s, dirs3 + 3 * i, rgb3 + 3 * i, pdf + i);
+}
+void orc_env_sample_batch(const orc_scene* s, const float* rnd, int64_t n, float* dirs3, float* rgb3, float* pdf) {
+    for (int64_t i = 0; i < n; i++) orc_env_sample(s, rnd[i], dirs3 + 3 * i, rgb3 + 3 * i, pdf + i);
+}
+void orc_material_eval_batch(const orc_material* m, const float* normal3, int32_t front_face, const float* in_dir3,
+                             const float* out_dirs3, int64_t n, float* f3, float* pdf) {
+    for (int64_t i = 0; i < n; i++) orc_material_eval(m, normal3, front_face, in_dir3, out_dirs3 + 3 * i, f3 + 3 * i, pdf + i);
+}
+void orc_material_sample_batch(const orc_material* m, const float* point3, const float* normal3, int32_t front_face,
+                               const float* in_dir3, const float* rnd4, int64_t n, float* out_origin3, float* out_dirs3, float* f3,
+                               float* pdf) { // four random numbers per sample (no material draws more)
+    for (int64_t i = 0; i < n; i++)
+        orc_material_sample(m, point3, normal3, front_face, in_dir3, rnd4 + 4 * i, out_origin3 + 3 * i, out_dirs3 + 3 * i, f3 + 3 * i, pdf + i);
+}
+
 uint32_t orc_rng_key(uint32_t pixel, uint32_t sample, uint32_t seed) { return rng_key(pixel, sample, seed); }
 float orc_rng_draw(uint32_t key, uint32_t counter) { return rng_float(key, counter); }
 

@@ -209,6 +209,15 @@ int32_t orc_material_sample(const orc_material* m, const float* point3, const fl
                             int32_t front_face, const float* in_dir3, const float* rnd,
                             float* out_origin3, float* out_dir3, float* f3, float* pdf);
 
+/* Batch forms (n directions / random numbers; rnd4 = four random numbers per sample). */
+void orc_env_eval_batch(const orc_scene* s, const float* dirs3, int64_t n, float* rgb3, float* pdf);
+void orc_env_sample_batch(const orc_scene* s, const float* rnd, int64_t n, float* dirs3, float* rgb3, float* pdf);
+void orc_material_eval_batch(const orc_material* m, const float* normal3, int32_t front_face, const float* in_dir3,
+                             const float* out_dirs3, int64_t n, float* f3, float* pdf);
+void orc_material_sample_batch(const orc_material* m, const float* point3, const float* normal3, int32_t front_face,
+                               const float* in_dir3, const float* rnd4, int64_t n, float* out_origin3, float* out_dirs3,
+                               float* f3, float* pdf);
+
 /* The counter-based random stream shared (by specification) with the GPU path. */
 uint32_t orc_rng_key(uint32_t pixel, uint32_t sample, uint32_t seed);
 float orc_rng_draw(uint32_t key, uint32_t counter);

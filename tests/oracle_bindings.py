@@ -90,6 +90,10 @@ def lib():
         L.orc_material_eval.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.orc_material_sample.argtypes = [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp]
         L.orc_material_sample.restype = i32
+        L.orc_env_eval_batch.argtypes = [C.POINTER(OrcScene), vp, i64, vp, vp]
+        L.orc_env_sample_batch.argtypes = [C.POINTER(OrcScene), vp, i64, vp, vp, vp]
+        L.orc_material_eval_batch.argtypes = [vp, vp, i32, vp, vp, i64, vp, vp]
+        L.orc_material_sample_batch.argtypes = [vp, vp, vp, i32, vp, vp, i64, vp, vp, vp, vp]
         L.orc_rng_key.argtypes = [u32, u32, u32]
         L.orc_rng_key.restype = u32
         L.orc_rng_draw.argtypes = [u32, u32]
@@ -381,3 +385,40 @@ def material_sample(mat, point, normal, front_face, in_dir, rnd):
     used = lib().orc_material_sample(_ptr(mat), _ptr(_f32(point)), _ptr(_f32(normal)), int(front_face), _ptr(_f32(in_dir)),
                                      _ptr(_f32(rnd)), _ptr(o), _ptr(d), _ptr(f), _ptr(pdf))
     return o, d, f, float(pdf[0]), used
+
+
+def env_eval_batch(scene, dirs):
+    """EnviormentLight::eval for n directions -> (rgb [n,3], pdf [n])."""
+    dirs = _f32(dirs).reshape(-1, 3)
+    rgb, pdf = np.zeros((len(dirs), 3), np.float32), np.zeros(len(dirs), np.float32)
+    lib().orc_env_eval_batch(C.byref(scene.c), _ptr(dirs), len(dirs), _ptr(rgb), _ptr(pdf))
+    return rgb, pdf
+
+
+def env_sample_batch(scene, rnd):
+    """EnviormentLight::sample_eval for n given random numbers -> (dirs [n,3], rgb [n,3], pdf [n])."""
+    rnd = _f32(rnd).ravel()
+    dirs, rgb, pdf = np.zeros((len(rnd), 3), np.float32), np.zeros((len(rnd), 3), np.float32), np.zeros(len(rnd), np.float32)
+    lib().orc_env_sample_batch(C.byref(scene.c), _ptr(rnd), len(rnd), _ptr(dirs), _ptr(rgb), _ptr(pdf))
+    return dirs, rgb, pdf
+
+
+def material_eval_batch(mat, normal, front_face, in_dir, out_dirs):
+    out_dirs = _f32(out_dirs).reshape(-1, 3)
+    f, pdf = np.zeros((len(out_dirs), 3), np.float32), np.zeros(len(out_dirs), np.float32)
+    mat = np.ascontiguousarray(mat, dtype=MATERIAL)
+    lib().orc_material_eval_batch(_ptr(mat), _ptr(_f32(normal)), int(front_face), _ptr(_f32(in_dir)), _ptr(out_dirs), len(out_dirs),
+                                  _ptr(f), _ptr(pdf))
+    return f, pdf
+
+
+def material_sample_batch(mat, point, normal, front_face, in_dir, rnd4):
+    """Sample_Eval for n samples, four random numbers each (draw order) -> (origins, dirs, f, pdf)."""
+    rnd4 = _f32(rnd4).reshape(-1, 4)
+    n = len(rnd4)
+    o, d, f = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    pdf = np.zeros(n, np.float32)
+    mat = np.ascontiguousarray(mat, dtype=MATERIAL)
+    lib().orc_material_sample_batch(_ptr(mat), _ptr(_f32(point)), _ptr(_f32(normal)), int(front_face), _ptr(_f32(in_dir)), _ptr(rnd4), n,
+                                    _ptr(o), _ptr(d), _ptr(f), _ptr(pdf))
+    return o, d, f, pdf
