@@ -215,7 +215,7 @@ typedef struct rt_camera {
 } rt_camera;
 
 #define RT_RENDER_CLEAR 1u      /* zero radiance_sum before accumulating      */
-#define RT_RENDER_DEVICE_OUT 2u /* radiance_sum is a device pointer           */
+#define RT_RENDER_DEVICE_OUT 2u /* radiance_sum is a device pointer (see rt_render: stream ordering is the caller's) */
 #define RT_RENDER_TIMING 4u     /* bracket every kernel with HIP events       */
 #define RT_RENDER_SERIAL 8u     /* one sample pass at a time on one stream (per-kernel times then are stand-alone times) */
 
@@ -310,7 +310,11 @@ int rt_trace_closest_noalloc(rt_scene* scene, const rt_ray* rays, int64_t n, rt_
  * (Scene.h:61-75), run get_ray_color (main.cpp:325-441) as a wavefront
  * (generate / closest-hit / shade+NEE / shadow / accumulate kernels) and add
  * the NaN-guarded sample (main.cpp:984-987) into radiance_sum[(y*width+x)*3],
- * y in raster order (the flip of main.cpp:990 happens in rt_resolve). */
+ * y in raster order (the flip of main.cpp:990 happens in rt_resolve).
+ * RT_RENDER_DEVICE_OUT: the library works on its own non-blocking streams, which nothing orders after work the caller has
+ * queued on other streams — fills or copies into radiance_sum (e.g. a torch.zeros) must have FINISHED before the call
+ * (synchronise that stream first); the call returns after its own work is complete, so the buffer may be read on any
+ * stream afterwards. */
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
               float* radiance_sum, rt_stats* stats);
 

@@ -134,6 +134,8 @@ def load_libraries():
     host.rth_scene_array.restype = vp
     host.rth_scene_info.argtypes = [vp, vp, vp, vp, vp, vp]
     host.rth_look_at.argtypes = [vp, vp, vp, vp]
+    host.rth_mat4_inverse.argtypes = [vp, vp]
+    host.rth_mat4_inverse.restype = f32
     host.rth_camera_init.argtypes = [vp, f32, i32, i32, i32, f32, C.POINTER(RtCamera)]
     host.rth_camera_ray.argtypes = [vp, f32, i32, i32, f32, f32, vp]
     host.rth_write_image.argtypes = [C.c_char_p, i32, i32, vp]
@@ -198,6 +200,15 @@ def look_at(eye, at, up):
     out = np.zeros(16, np.float32)
     host.rth_look_at(_ptr(_f32(eye, 3)), _ptr(_f32(at, 3)), _ptr(_f32(up, 3)), _ptr(out))
     return out
+
+
+def mat4_inverse(m16):
+    """inverse(mat4) of the host mirror (Math.h:454-542: fp32 adjugate over determinant; a singular matrix comes back
+    unchanged) -> (inverse as 16 column-major floats, determinant)."""
+    _, host = load_libraries()
+    out = np.zeros(16, np.float32)
+    det = host.rth_mat4_inverse(_ptr(_f32(m16, 16)), _ptr(out))
+    return out, float(det)
 
 
 def camera(view16, fov_deg, width, height, filter=FILTER_GAUSSIAN, filter_param=0.5):

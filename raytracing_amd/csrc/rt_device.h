@@ -416,7 +416,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                     const int far = left_first ? rref : lref;
                     if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = far;
                     else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
-                    sp++;
+                    if (sp < RT_STACK_TOTAL) sp++; // (rt_scene_create refuses deeper trees; were one to get here, the entry is lost, never memory)
                 } else if (!lh && !rh) { // pop, or finish on an empty stack
                     if (sp == 0) {
                         cur = RT_CUR_FINISH;
@@ -549,7 +549,7 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                     const int far = left_first ? rref : lref;
                     if (sp < RT_SHORT_STACK) lds[sp * RT_TRAV_BLOCK] = far;
                     else if (sp < RT_STACK_TOTAL) spill[sp - RT_SHORT_STACK] = far;
-                    sp++;
+                    if (sp < RT_STACK_TOTAL) sp++; // (rt_scene_create refuses deeper trees; were one to get here, the entry is lost, never memory)
                 } else if (!lh && !rh) {
                     if (sp == 0) {
                         cur = RT_CUR_FINISH;

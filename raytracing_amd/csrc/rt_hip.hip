@@ -24,6 +24,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace rtd;
@@ -756,6 +757,28 @@ int rt_device_count(void) {
     return n;
 }
 
+// Depth (inner nodes on the longest root-to-leaf path) of the tree of pair records under `root`; -1 when a record is
+// reached twice (a cycle, or subtrees shared between parents: the walks assume a tree).  A walk's stack holds at most one
+// entry per inner node on the current path, so a tree within the reference's own stack depth (Object.h:275, Scene.cpp:19)
+// cannot overrun it.  seen: one flag per record, shared by all the roots of a scene.
+static int pair_tree_depth(const rt_bvh_pair* pairs, int64_t n_pairs, int32_t root, std::vector<uint8_t>& seen) {
+    if (root < 0) return 0;
+    int depth = 0;
+    std::vector<std::pair<int32_t, int>> todo;
+    todo.push_back({root, 1});
+    while (!todo.empty()) {
+        const auto [r, d] = todo.back();
+        todo.pop_back();
+        if (r < 0 || r >= n_pairs) continue; // (leaf; ranges were checked by the caller)
+        if (seen[(size_t)r]) return -1;
+        seen[(size_t)r] = 1;
+        depth = std::max(depth, d);
+        todo.push_back({pairs[r].lref, d + 1});
+        todo.push_back({pairs[r].rref, d + 1});
+    }
+    return depth;
+}
+
 // tl == nullptr: the flat scene of rt_scene_create; otherwise the two-level scene of rt_scene_create_instanced
 static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int device, rt_scene** out) {
     if (!d || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
@@ -778,6 +801,27 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
     }
     if (d->n_tris > 0 && !(d->tris[d->n_tris - 1].tri_id & RT_TRI_LEAF_END))
         return fail(RT_ERR_INVALID, "rt_scene_create: last triangle must end a leaf");
+    {   // the walks' stacks: 64 entries (flat, the reference's own: Object.h:275), 128 in a two-level scene = 63 for the TLAS
+        // (Scene.cpp:19 has 64) + the mesh's exit marker + 64 for the mesh
+        std::vector<uint8_t> seen((size_t)d->n_pairs, 0);
+        if (!tl) {
+            const int depth = pair_tree_depth(d->pairs, d->n_pairs, d->root_ref, seen);
+            if (depth < 0) return fail(RT_ERR_INVALID, "rt_scene_create: the pair records do not form a tree (a record is reached twice)");
+            if (depth > RT_STACK_TOTAL) return fail(RT_ERR_LIMIT, "rt_scene_create: BVH deeper than 64 levels (the traversal stack of Object.h:275)");
+        } else {
+            std::vector<int32_t> roots;
+            for (int32_t i = 0; i < tl->n_instances && tl->instances; i++)
+                if (tl->instances[i].geometry == RT_GEO_MESH && tl->instances[i].blas_root >= 0 && tl->instances[i].blas_root < d->n_pairs)
+                    roots.push_back(tl->instances[i].blas_root);
+            std::sort(roots.begin(), roots.end());
+            roots.erase(std::unique(roots.begin(), roots.end()), roots.end());
+            for (int32_t r : roots) {
+                const int depth = pair_tree_depth(d->pairs, d->n_pairs, r, seen);
+                if (depth < 0) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: the mesh pair records do not form trees (a record is reached twice)");
+                if (depth > RT_STACK_TOTAL) return fail(RT_ERR_LIMIT, "rt_scene_create_instanced: a mesh BVH is deeper than 64 levels (Object.h:275)");
+            }
+        }
+    }
     for (int64_t i = 0; i < d->n_tris && !tl; i++) {
         if (d->tris[i].material < 0 || d->tris[i].material >= d->n_materials)
             return fail(RT_ERR_INVALID, "rt_scene_create: triangle material out of range");
@@ -793,6 +837,12 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
         for (int64_t i = 0; i < tl->n_pairs; i++)
             if (!tl_ref_ok(tl->pairs[i].lref) || !tl_ref_ok(tl->pairs[i].rref))
                 return fail(RT_ERR_INVALID, "rt_scene_create_instanced: TLAS child ref out of range");
+        {
+            std::vector<uint8_t> seen((size_t)tl->n_pairs, 0);
+            const int depth = pair_tree_depth(tl->pairs, tl->n_pairs, tl->root_ref, seen);
+            if (depth < 0) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: the TLAS pair records do not form a tree");
+            if (depth > RT_STACK_TOTAL - 1) return fail(RT_ERR_LIMIT, "rt_scene_create_instanced: TLAS deeper than 63 levels");
+        }
         for (int32_t i = 0; i < tl->n_instances; i++) {
             const rt_instance& I = tl->instances[i];
             if (I.geometry < RT_GEO_MESH || I.geometry > RT_GEO_CYLINDER) return fail(RT_ERR_INVALID, "rt_scene_create_instanced: unknown geometry");

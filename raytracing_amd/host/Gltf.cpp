@@ -296,6 +296,13 @@ struct Importer {
                          nrm.component == 5126 && nrm.width == 3;
             bool has_uv = prim["attributes"].has("TEXCOORD_0") && view_accessor(doc, prim["attributes"]["TEXCOORD_0"].integer(-1), &uv) &&
                           uv.component == 5126 && uv.width == 2;
+            // a malformed file must fail the load, not read past an accessor: attribute accessors hold one element per
+            // vertex, indices come in threes and stay below the vertex count, the material index is not negative
+            const int material = prim["material"].integer(0);
+            if ((has_n && nrm.count < pos.count) || (has_uv && uv.count < pos.count) || material < 0) {
+                ok = false;
+                continue;
+            }
             const uint32_t vertexStart = (uint32_t)model.verts.size();
             model.verts.resize(model.verts.size() + pos.count);
             for (size_t v = 0; v < pos.count; v++) {
@@ -320,6 +327,11 @@ struct Importer {
                     ok = false;
                     continue;
                 }
+                if (idx.component != 5125 && idx.component != 5123 && idx.component != 5121) {
+                    ok = false;
+                    model.verts.resize(vertexStart);
+                    continue;
+                }
                 indices.resize(idx.count);
                 for (size_t k = 0; k < idx.count; k++) {
                     const uint8_t* q = idx.data + k * idx.stride;
@@ -331,9 +343,15 @@ struct Importer {
                 indices.resize(pos.count);
                 for (size_t k = 0; k < pos.count; k++) indices[k] = (uint32_t)k;
             }
+            bool in_range = indices.size() % 3 == 0;
+            for (size_t k = 0; in_range && k < indices.size(); k++) in_range = indices[k] < pos.count;
+            if (!in_range) {
+                ok = false;
+                model.verts.resize(vertexStart);
+                continue;
+            }
             const size_t triStart = model.triangles.size();
             model.triangles.resize(triStart + indices.size() / 3);
-            const int material = prim["material"].integer(0);
             for (size_t t = 0; t < indices.size() / 3; t++) {
                 MeshTriangle& tri = model.triangles[triStart + t];
                 for (int c = 0; c < 3; c++) tri.indicies[c] = indices[3 * t + c] + vertexStart;
@@ -426,7 +444,7 @@ bool Scene::load_from_gltf(const std::string& gltfPath) { // Scene.cpp:196-214
     const Json& roots = scenes[(size_t)doc.root["scene"].integer(0)]["nodes"]; // all roots, not nodes.at(0) (Scene.cpp:212)
     for (size_t i = 0; i < roots.size(); i++) imp.visit(roots[i].integer(-1), mat4(1.f), 0);
     if (!imp.ok) {
-        std::printf("Couldn't load gltf model: unsupported accessor layout\n");
+        std::printf("Couldn't load gltf model: unsupported or inconsistent accessor layout\n");
         return false;
     }
     for (MeshTriangle& t : sceneMergedMesh.triangles)

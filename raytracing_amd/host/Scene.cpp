@@ -220,6 +220,23 @@ Scene::~Scene() {
     delete environment;
 }
 
+bool Scene::replace_material(size_t index, Material* m) {
+    if (index >= materials.size() || !m) {
+        delete m;
+        return false;
+    }
+    Material* old = materials[index];
+    if (old == m) return true;
+    for (Instance& i : instances)
+        if (i.material == old) i.material = m;
+    for (Instance& l : lights)
+        if (l.material == old) l.material = m;
+    for (Material*& other : materials) // (a material listed twice stays one object)
+        if (other == old) other = m;
+    delete old;
+    return true;
+}
+
 void Scene::set_environment(HDRImage* img, float degrees_offset) {
     delete environment;
     environment = img;

@@ -201,6 +201,9 @@ public:
     // two emissive triangles into sceneMergedMesh + the sampled light.
     void add_rectangle_light(vec3 normal, float u_length, float v_length, vec3 emit, const mat4& transform);
     void set_environment(HDRImage* img, float degrees_offset = 0.f); // takes ownership
+    // materials[index] = m (takes ownership): every Instance in `instances` and `lights` that holds the old material is
+    // moved to the new one before the old one is freed; false (and m freed) when index is out of range
+    bool replace_material(size_t index, Material* m);
     // Instance(TriangleMesh, material, transform) of the legacy design (Object.h:364-423, main.cpp:456-470), flattened
     // at scene set-up: the mesh's triangles enter sceneMergedMesh in world space — positions through
     // Transform::to_world_point, normals through normalize(to_world_normal) exactly as Instance::intersect reports

@@ -158,9 +158,7 @@ int32_t rth_scene_set_material(rth_scene* s, int32_t index, const rt_material* r
     if (index < 0 || (size_t)index >= s->scene.materials.size()) return 0;
     Material* m = material_from_record(*rec);
     if (!m) return 0;
-    delete s->scene.materials[index];
-    s->scene.materials[index] = m;
-    return 1;
+    return s->scene.replace_material((size_t)index, m) ? 1 : 0; // instances placed with the old material follow it
 }
 
 void rth_scene_add_rect_light(rth_scene* s, const float* normal3, float u_length, float v_length, const float* emit3, const float* transform16) {
@@ -269,6 +267,14 @@ void rth_scene_info(rth_scene* s, int32_t* info4, float* env_total, float* env_o
     *env_offset = sc.environment_offset;
     std::memcpy(cam_view16, sc.sceneCameraView.m, sizeof(float) * 16);
     *cam_fov = sc.sceneCameraFov;
+}
+
+// inverse / determinant of a column-major 4x4 (Math.h:425-542); returns the determinant
+float rth_mat4_inverse(const float* m16, float* out16) {
+    const mat4 a = mat4::from_columns(m16);
+    const mat4 r = inverse(a);
+    for (int i = 0; i < 16; i++) out16[i] = r.m[i];
+    return determinant(a);
 }
 
 void rth_look_at(const float* eye3, const float* at3, const float* up3, float* view16) {

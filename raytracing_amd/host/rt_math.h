@@ -90,37 +90,64 @@ inline mat4 transpose(const mat4& a) {
     return r;
 }
 
-// General 4x4 inverse by Gauss-Jordan in double (host set-up only; the results
-// are data handed to both the GPU path and the oracle, not hot-path arithmetic).
-inline mat4 inverse(const mat4& a) {
-    double w[4][8];
-    for (int r = 0; r < 4; r++)
-        for (int c = 0; c < 4; c++) {
-            w[r][c] = a.m[c * 4 + r];
-            w[r][c + 4] = (r == c) ? 1.0 : 0.0;
-        }
-    for (int i = 0; i < 4; i++) {
-        int p = i;
-        for (int r = i + 1; r < 4; r++)
-            if (std::fabs(w[r][i]) > std::fabs(w[p][i])) p = r;
-        if (w[p][i] == 0.0) return a; // singular: returned unchanged, like Math.h:457-458
-        if (p != i)
-            for (int c = 0; c < 8; c++) {
-                double t = w[i][c];
-                w[i][c] = w[p][c];
-                w[p][c] = t;
-            }
-        double d = w[i][i];
-        for (int c = 0; c < 8; c++) w[i][c] /= d;
-        for (int r = 0; r < 4; r++)
-            if (r != i) {
-                double f = w[r][i];
-                for (int c = 0; c < 8; c++) w[r][c] -= f * w[i][c];
-            }
+// determinant / inverse as the reference evaluates them (Math.h:425-542): fp32 throughout, the adjugate over the
+// determinant, every cofactor a left-to-right sum of six (the determinant: twenty-four) left-to-right products, in the
+// reference's term order — so Transform::inv_m and the camera chain carry the reference's bits.  The terms are kept as
+// tables of signed element indices (column-major, Math.h:341-346).
+namespace detail {
+struct Term3 { int8_t sign, a, b, c; };
+struct Term4 { int8_t sign, a, b, c, d; };
+constexpr Term4 kDet[24] = {
+    {+1, 12, 9, 6, 3},  {-1, 8, 13, 6, 3},  {-1, 12, 5, 10, 3}, {+1, 4, 13, 10, 3}, {+1, 8, 5, 14, 3},  {-1, 4, 9, 14, 3},
+    {-1, 12, 9, 2, 7},  {+1, 8, 13, 2, 7},  {+1, 12, 1, 10, 7}, {-1, 0, 13, 10, 7}, {-1, 8, 1, 14, 7},  {+1, 0, 9, 14, 7},
+    {+1, 12, 5, 2, 11}, {-1, 4, 13, 2, 11}, {-1, 12, 1, 6, 11}, {+1, 0, 13, 6, 11}, {+1, 4, 1, 14, 11}, {-1, 0, 5, 14, 11},
+    {-1, 8, 5, 2, 15},  {+1, 4, 9, 2, 15},  {+1, 8, 1, 6, 15},  {-1, 0, 9, 6, 15},  {-1, 4, 1, 10, 15}, {+1, 0, 5, 10, 15}};
+constexpr Term3 kAdj[16][6] = {
+    {{+1, 9, 14, 7}, {-1, 13, 10, 7}, {+1, 13, 6, 11}, {-1, 5, 14, 11}, {-1, 9, 6, 15}, {+1, 5, 10, 15}},
+    {{+1, 13, 10, 3}, {-1, 9, 14, 3}, {-1, 13, 2, 11}, {+1, 1, 14, 11}, {+1, 9, 2, 15}, {-1, 1, 10, 15}},
+    {{+1, 5, 14, 3}, {-1, 13, 6, 3}, {+1, 13, 2, 7}, {-1, 1, 14, 7}, {-1, 5, 2, 15}, {+1, 1, 6, 15}},
+    {{+1, 9, 6, 3}, {-1, 5, 10, 3}, {-1, 9, 2, 7}, {+1, 1, 10, 7}, {+1, 5, 2, 11}, {-1, 1, 6, 11}},
+    {{+1, 12, 10, 7}, {-1, 8, 14, 7}, {-1, 12, 6, 11}, {+1, 4, 14, 11}, {+1, 8, 6, 15}, {-1, 4, 10, 15}},
+    {{+1, 8, 14, 3}, {-1, 12, 10, 3}, {+1, 12, 2, 11}, {-1, 0, 14, 11}, {-1, 8, 2, 15}, {+1, 0, 10, 15}},
+    {{+1, 12, 6, 3}, {-1, 4, 14, 3}, {-1, 12, 2, 7}, {+1, 0, 14, 7}, {+1, 4, 2, 15}, {-1, 0, 6, 15}},
+    {{+1, 4, 10, 3}, {-1, 8, 6, 3}, {+1, 8, 2, 7}, {-1, 0, 10, 7}, {-1, 4, 2, 11}, {+1, 0, 6, 11}},
+    {{+1, 8, 13, 7}, {-1, 12, 9, 7}, {+1, 12, 5, 11}, {-1, 4, 13, 11}, {-1, 8, 5, 15}, {+1, 4, 9, 15}},
+    {{+1, 12, 9, 3}, {-1, 8, 13, 3}, {-1, 12, 1, 11}, {+1, 0, 13, 11}, {+1, 8, 1, 15}, {-1, 0, 9, 15}},
+    {{+1, 4, 13, 3}, {-1, 12, 5, 3}, {+1, 12, 1, 7}, {-1, 0, 13, 7}, {-1, 4, 1, 15}, {+1, 0, 5, 15}},
+    {{+1, 8, 5, 3}, {-1, 4, 9, 3}, {-1, 8, 1, 7}, {+1, 0, 9, 7}, {+1, 4, 1, 11}, {-1, 0, 5, 11}},
+    {{+1, 12, 9, 6}, {-1, 8, 13, 6}, {-1, 12, 5, 10}, {+1, 4, 13, 10}, {+1, 8, 5, 14}, {-1, 4, 9, 14}},
+    {{+1, 8, 13, 2}, {-1, 12, 9, 2}, {+1, 12, 1, 10}, {-1, 0, 13, 10}, {-1, 8, 1, 14}, {+1, 0, 9, 14}},
+    {{+1, 12, 5, 2}, {-1, 4, 13, 2}, {-1, 12, 1, 6}, {+1, 0, 13, 6}, {+1, 4, 1, 14}, {-1, 0, 5, 14}},
+    {{+1, 4, 9, 2}, {-1, 8, 5, 2}, {+1, 8, 1, 6}, {-1, 0, 9, 6}, {-1, 4, 1, 10}, {+1, 0, 5, 10}}};
+} // namespace detail
+
+inline float determinant(const mat4& a) { // Math.h:425-452
+    const float* m = a.m;
+    float acc = 0.f;
+    for (int k = 0; k < 24; k++) {
+        const detail::Term4& t = detail::kDet[k];
+        const float p = ((m[t.a] * m[t.b]) * m[t.c]) * m[t.d];
+        if (k == 0) acc = p; // the first term is positive
+        else acc = t.sign > 0 ? acc + p : acc - p;
     }
+    return acc;
+}
+inline mat4 inverse(const mat4& a) { // Math.h:454-542; a singular matrix is returned unchanged (457-458)
+    const float det = determinant(a);
+    if (det == 0.f) return a;
+    const float inv_det = 1.f / det;
+    const float* m = a.m;
     mat4 r;
-    for (int rr = 0; rr < 4; rr++)
-        for (int c = 0; c < 4; c++) r.m[c * 4 + rr] = (float)w[rr][c + 4];
+    for (int e = 0; e < 16; e++) {
+        float acc = 0.f;
+        for (int k = 0; k < 6; k++) {
+            const detail::Term3& t = detail::kAdj[e][k];
+            const float p = (m[t.a] * m[t.b]) * m[t.c];
+            if (k == 0) acc = p; // every cofactor starts with a positive term
+            else acc = t.sign > 0 ? acc + p : acc - p;
+        }
+        r.m[e] = inv_det * acc;
+    }
     return r;
 }
 

@@ -100,6 +100,64 @@ def test_flat_description_checks(rta):
     assert rc == RT_ERR_INVALID and "light" in msg
 
 
+def _chain(rta, depth):
+    """A degenerate BVH: `depth` pair records in a chain (left child = a leaf, right child = the next record), one
+    triangle per leaf — what a caller-built tree over sorted, nested primitives can look like."""
+    n_tris = depth + 1
+    pairs = np.zeros(depth, rta.PAIR)
+    pairs["lmin"], pairs["lmax"], pairs["rmin"], pairs["rmax"] = -1, 1, -1, 1
+    for k in range(depth):
+        pairs["lref"][k] = ~k
+        pairs["rref"][k] = k + 1 if k + 1 < depth else ~depth
+    tris = np.zeros(n_tris, rta.FLAT_TRI)
+    tris["e1"], tris["e2"] = (1, 0, 0), (0, 1, 0)
+    tris["tri_id"] = np.arange(n_tris, dtype=np.uint32) | np.uint32(0x80000000)
+    tris["light"] = -1
+    normals = np.zeros(n_tris, rta.FLAT_NORMALS)
+    mats = rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5))
+    d = SceneDesc()
+    d.root_ref = 0
+    d.n_pairs, d.pairs = depth, pairs.ctypes.data
+    d.n_tris, d.tris, d.normals = n_tris, tris.ctypes.data, normals.ctypes.data
+    d.n_materials, d.materials = 1, mats.ctypes.data
+    return (pairs, tris, normals, mats), d
+
+
+def test_tree_depth_and_shape_checks(rta):
+    """The walks keep the reference's 64-entry stack (Object.h:275): a tree deeper than that is refused with RT_ERR_LIMIT
+    (it would have overrun the reference's own stack too), a record reached twice (cycle / shared subtree) with
+    RT_ERR_INVALID — error codes on the host, not a wild read in a kernel."""
+    keep, d = _chain(rta, 64)
+    rc, msg = _create(rta, d)
+    assert _good(rta, rc), msg
+    keep, d = _chain(rta, 70)
+    rc, msg = _create(rta, d)
+    assert rc == RT_ERR_LIMIT and "deeper than 64" in msg
+    keep, d = _chain(rta, 10)
+    keep[0]["rref"][9] = 3  # a cycle
+    rc, msg = _create(rta, d)
+    assert rc == RT_ERR_INVALID and "tree" in msg
+    keep, d = _chain(rta, 10)
+    keep[0]["lref"][2] = 7  # record 7 has two parents
+    rc, msg = _create(rta, d)
+    assert rc == RT_ERR_INVALID and "tree" in msg
+    # two-level: the TLAS may be 63 deep (its entries share the stack with a mesh's exit marker and the mesh's 64)
+    sc, a, dd, t = _two_level(rta)
+    deep = np.zeros(70, rta.PAIR)
+    for k in range(70):
+        deep["lref"][k] = ~0
+        deep["rref"][k] = k + 1 if k + 1 < 70 else ~1
+    t.n_pairs, t.pairs = 70, deep.ctypes.data
+    rc, msg = _create(rta, dd, t)
+    assert rc == RT_ERR_LIMIT and "TLAS deeper" in msg
+    sc, a, dd, t = _two_level(rta)
+    mesh_pairs = a["FLAT_PAIRS"]
+    assert len(mesh_pairs) > 4
+    mesh_pairs["rref"][len(mesh_pairs) - 1] = 0  # the mesh tree bites its own root
+    rc, msg = _create(rta, dd, t)
+    assert rc == RT_ERR_INVALID and "trees" in msg
+
+
 def test_two_level_description_checks(rta):
     sc, a, d, t = _two_level(rta)
     rc, msg = _create(rta, d, t)

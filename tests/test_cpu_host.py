@@ -184,6 +184,47 @@ def test_gltf_loader_rejects_garbage(rta, tmp_path):
         rta.Scene().load_gltf(str(tmp_path / "missing.glb"))
 
 
+def _tiny_gltf(tmp_path, name, indices, n_normals=3, material=0, index_type=5123):
+    """A one-triangle .gltf with an embedded base64 buffer: 3 positions, n_normals normals, the given indices."""
+    import base64
+    import json
+    import struct
+
+    pos = struct.pack("<9f", 0, 0, 0, 1, 0, 0, 0, 1, 0)
+    nrm = struct.pack(f"<{3 * n_normals}f", *([0, 0, 1] * n_normals))
+    idx = struct.pack({5123: f"<{len(indices)}H", 5125: f"<{len(indices)}I", 5126: f"<{len(indices)}f"}[index_type], *indices)
+    idx += b"\0" * (-len(idx) % 4)
+    blob = pos + nrm + idx
+    doc = {
+        "asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+        "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1}, "indices": 2, "material": material}]}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.5, 0.5, 0.5, 1]}}],
+        "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+        "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": len(nrm)},
+                        {"buffer": 0, "byteOffset": 36 + len(nrm), "byteLength": len(idx)}],
+        "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"},
+                      {"bufferView": 1, "componentType": 5126, "count": n_normals, "type": "VEC3"},
+                      {"bufferView": 2, "componentType": index_type, "count": len(indices), "type": "SCALAR"}],
+    }
+    path = tmp_path / name
+    path.write_text(json.dumps(doc))
+    return str(path)
+
+
+def test_gltf_loader_checks_indices_and_accessor_counts(rta, tmp_path):
+    """A well-formed one-triangle file loads; an index beyond the vertex count, an index count that is not a multiple of
+    three, a NORMAL accessor shorter than POSITION, a negative material and a float index accessor all fail the load
+    (the reference asserts on malformed files, Scene.cpp:100,168) instead of reading past a buffer."""
+    good = rta.Scene()
+    good.load_gltf(_tiny_gltf(tmp_path, "good.gltf", [0, 1, 2]))
+    assert len(good.array(rta.ARR_TRIS)) == 1 and len(good.array(rta.ARR_VERTS)) == 3
+    for name, kw in (("oob.gltf", dict(indices=[0, 1, 7])), ("ragged.gltf", dict(indices=[0, 1, 2, 0])),
+                     ("short_normals.gltf", dict(indices=[0, 1, 2], n_normals=2)), ("neg_mat.gltf", dict(indices=[0, 1, 2], material=-3)),
+                     ("float_idx.gltf", dict(indices=[0, 1, 2], index_type=5126))):
+        with pytest.raises(rta.RtError):
+            rta.Scene().load_gltf(_tiny_gltf(tmp_path, name, **kw))
+
+
 def test_host_camera_matches_oracle(rta, orc):
     view = rta.look_at((-1.0, 0.5, 0.8), (0.0, 0.2, 0.0), (0, 1, 0))  # main.cpp:719
     assert np.array_equal(view, orc.look_at((-1.0, 0.5, 0.8), (0.0, 0.2, 0.0), (0, 1, 0)))
@@ -288,3 +329,36 @@ def test_image_writers_round_trip(rta, tmp_path):
         assert np.array_equal(px, img)
     with pytest.raises(OSError):
         rta.write_image(str(tmp_path / "no_such_dir" / "x.png"), img)
+
+
+def test_inverse_is_the_references_fp32_adjugate(rta):
+    """inverse(mat4) (Math.h:454-542): fp32 cofactors over an fp32 determinant, terms summed left to right in the
+    reference's order; det == 0 returns the matrix unchanged.  Known answers + the first cofactor recomputed by hand."""
+    f = np.float32
+    # translation and scale: exact
+    m = np.eye(4, dtype=np.float32)
+    m[:3, 3] = (1.5, -2.0, 0.25)
+    m[0, 0], m[1, 1], m[2, 2] = 2.0, 4.0, 0.5
+    inv, det = rta.mat4_inverse(m.T.reshape(-1))
+    assert det == 4.0
+    want = np.eye(4)
+    want[0, 0], want[1, 1], want[2, 2] = 0.5, 0.25, 2.0
+    want[:3, 3] = (-0.75, 0.5, -0.5)
+    assert np.array_equal(inv.reshape(4, 4).T, want.astype(np.float32))
+    # a general affine matrix: close to the float64 inverse, and NOT what a double-precision elimination rounds to everywhere
+    rng = np.random.default_rng(4)
+    a = np.eye(4, dtype=np.float32)
+    a[:3, :] = rng.normal(size=(3, 4)).astype(np.float32)
+    c = a.T.reshape(-1).copy()  # column-major: c[4 * col + row]
+    inv, det = rta.mat4_inverse(c)
+    exact = np.linalg.inv(a.astype(np.float64))
+    assert np.allclose(inv.reshape(4, 4).T, exact, rtol=2e-5, atol=2e-6) and det == pytest.approx(np.linalg.det(a.astype(np.float64)), rel=1e-5)
+    # element 0 by hand, in the reference's order (Math.h:461-465) with fp32 rounding after every operation
+    t = lambda i, j, k: f(f(c[i] * c[j]) * c[k])
+    e0 = f(f(f(f(f(t(9, 14, 7) - t(13, 10, 7)) + t(13, 6, 11)) - t(5, 14, 11)) - t(9, 6, 15)) + t(5, 10, 15))
+    assert inv[0] == f(f(f(1.0) / f(det)) * e0)
+    # singular: unchanged (Math.h:457-458)
+    s = np.zeros(16, np.float32)
+    s[0] = s[5] = 1.0
+    out, det = rta.mat4_inverse(s)
+    assert det == 0.0 and np.array_equal(out, s)

@@ -142,3 +142,28 @@ def test_cpp_scene_script_compiles_against_the_host_mirror(tmp_path):
     """a scene script in the reference's own shape (Instance(new Sphere(...), material, offset), ...)
     compiles and links against librt_host.so / librt_hip.so."""
     assert _build_example(tmp_path)
+
+
+def test_set_material_after_instances_were_placed(rta):
+    """Scene.set_material on a slot that Instances already reference (and a Rectangle light in both lists): the instances
+    follow the new material; flatten finds it at the same index (no dangling pointer, no duplicate record)."""
+    sc = rta.Scene()
+    a = sc.add_material(rta.material(rta.MAT_MATTE, (0.1, 0.2, 0.3)))
+    e = sc.add_material(rta.material(rta.MAT_EMISSIVE, (5, 5, 5)))
+    eye = np.eye(4, dtype=np.float32).reshape(-1)
+    sc.add_primitive_instance(rta.GEO_SPHERE, (0.5,), a, eye)
+    sc.add_primitive_instance(rta.GEO_BOX, (1, 1, 1), a, eye)
+    up = np.eye(4, dtype=np.float32)
+    up[1, 3] = 3.0
+    sc.add_primitive_instance(rta.GEO_RECTANGLE, (0, -1, 0, 0.5, 0.5), e, up.T.reshape(-1), light=True)
+    sc.set_material(a, rta.material(rta.MAT_GGX, s=(0.3, 0.0)))
+    sc.set_material(e, rta.material(rta.MAT_EMISSIVE, (9, 8, 7)))
+    sc.build()
+    mats, inst, lights = sc.array(rta.ARR_MATERIALS), sc.array(rta.ARR_INSTANCES), sc.array(rta.ARR_LIGHTS)
+    assert len(mats) == 2 and mats["type"].tolist() == [rta.MAT_GGX, rta.MAT_EMISSIVE]
+    assert inst["material"].tolist() == [a, a, e] and mats["s"][a][0] == np.float32(0.3)
+    assert len(lights) == 1 and lights["material"][0] == e and mats["c0"][e].tolist() == [9, 8, 7]
+    sc.set_material(a, rta.material(rta.MAT_MATTE, (0.5, 0.5, 0.5)))  # and again, after a flatten
+    sc.build()
+    assert sc.array(rta.ARR_MATERIALS)["type"].tolist() == [rta.MAT_MATTE, rta.MAT_EMISSIVE]
+    sc.close()

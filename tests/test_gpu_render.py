@@ -103,3 +103,25 @@ def test_no_env_no_light(rta, orc, gpu):
     cam = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, 16, 16)
     img, st = sc.render(cam, 16, 16, spp=2, max_depth=3)
     assert not img.any() and st["rays_shadow"] == 0
+
+
+def test_device_out_equals_host_out(rta, orc, gpu):
+    """RT_RENDER_DEVICE_OUT (the caller's HBM buffer, synchronised before the call as include/rt_hip.h asks) accumulates
+    the same sums as the host-buffer form, over two calls into one buffer."""
+    import torch
+
+    sc = scenes.quad_room(rta)
+    sc.build()
+    sc.upload(gpu)
+    w, h = 40, 24
+    cam = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, w, h)
+    host, _ = sc.render(cam, w, h, spp=6, max_depth=4, seed=8, spp_total=12)
+    sc.render(cam, w, h, spp=6, max_depth=4, seed=8, spp_begin=6, spp_total=12, out=host)
+    dev = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    sc.render(cam, w, h, spp=6, max_depth=4, seed=8, spp_total=12, device_out=dev.data_ptr())
+    sc.render(cam, w, h, spp=6, max_depth=4, seed=8, spp_begin=6, spp_total=12, device_out=dev.data_ptr())
+    assert np.array_equal(dev.cpu().numpy(), host)
+    sc.render(cam, w, h, spp=6, max_depth=4, seed=8, spp_total=12, device_out=dev.data_ptr(), clear=True)
+    first, _ = sc.render(cam, w, h, spp=6, max_depth=4, seed=8, spp_total=12)
+    assert np.array_equal(dev.cpu().numpy(), first)
