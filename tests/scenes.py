@@ -143,7 +143,7 @@ def cornell_with_instances(rta, n_lat, n_lon, copies, seed=99):
     return sc
 
 
-def sphere_field(rta, n_spheres=10_000, n_lat=16, n_lon=32, seed=1234):
+def sphere_field(rta, n_spheres=10_000, n_lat=16, n_lon=32, seed=1234, grid=(22, 22, 21)):
     """BASELINE config 4 geometry: n_spheres tessellated spheres (2 n_lon (n_lat - 1) triangles each: 960 -> 9.6 M for
     10 000) on a jittered 22 x 22 x 21 grid in the unit box, one Lambert and one GGX material, a rectangle light on top."""
     rng = np.random.default_rng(seed)
@@ -151,7 +151,7 @@ def sphere_field(rta, n_spheres=10_000, n_lat=16, n_lon=32, seed=1234):
     sc.add_material(rta.material(rta.MAT_MATTE, (0.7, 0.7, 0.7)))
     sc.add_material(rta.material(rta.MAT_GGX, s=(0.4, 0.0)))
     v, t = uv_sphere(rta, n_lat, n_lon)
-    nx, ny, nz = 22, 22, 21
+    nx, ny, nz = grid  # (a smaller grid = fewer, larger spheres: the same picture in small)
     cells = rng.permutation(nx * ny * nz)[:n_spheres]
     for k, c in enumerate(cells):
         ix, iy, iz = c % nx, (c // nx) % ny, c // (nx * ny)
