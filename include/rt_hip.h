@@ -318,6 +318,14 @@ int rt_trace_closest_noalloc(rt_scene* scene, const rt_ray* rays, int64_t n, rt_
 int rt_render(rt_scene* scene, const rt_camera* cam, const rt_options* opt,
               float* radiance_sum, rt_stats* stats);
 
+/* rt_render over a LIST of tiles in one call: tiles_xyxy = n_tiles x (x0, y0, x1, y1), pairwise disjoint rectangles inside
+ * the raster (overlap is refused: RT_ERR_INVALID); opt->x0..y1 are ignored.  The reference hands 16x16 tiles to its threads
+ * one at a time (TileQueue, main.cpp:904-935); a GPU needs millions of paths in flight, so a rank of an image-tile-sharded
+ * render (SURVEY 8 e: interleaved 64x64 tiles, tile t -> GPU t mod G) passes ALL its tiles at once.  Every pixel gets
+ * exactly the sums rt_render gives it (the random streams are keyed by raster position and sample index). */
+int rt_render_tiles(rt_scene* scene, const rt_camera* cam, const rt_options* opt, const int32_t* tiles_xyxy, int32_t n_tiles,
+                    float* radiance_sum, rt_stats* stats);
+
 /* Replaces Renderer::add_to_buffer (main.cpp:865-877) for the whole image:
  * 1/spp, pow(1/gamma), clamp*255, row H-y-1.  Host pointers. */
 int rt_resolve(rt_scene* scene, const float* radiance_sum, int32_t width, int32_t height,
@@ -325,6 +333,35 @@ int rt_resolve(rt_scene* scene, const float* radiance_sum, int32_t width, int32_
 
 /* Blocks until all work queued on the scene's stream has finished. */
 int rt_scene_sync(rt_scene* scene);
+
+/* ---- multi-GPU: the frame's one reduce (SURVEY 8 e).  The reference has no counterpart (one process, std::thread over
+ * tiles: main.cpp:954-1005); these close a frame whose sample passes or image tiles were rendered by several GPUs, each
+ * into its own W*H*3 fp32 buffer: ONE sum into the root's buffer over RCCL / xGMI.  RCCL is loaded at run time; nothing
+ * here is needed, or touched, for one GPU. */
+typedef struct rt_comm rt_comm; /* opaque: one rank of a communicator, bound to one GPU */
+#define RT_COMM_ID_BYTES 128
+
+/* Rank 0 makes the id, every rank receives it by whatever channel the host has (a file, MPI, torch.distributed, ...). */
+int rt_comm_unique_id(uint8_t* id128);
+/* One rank per process (or thread): collective over all `world` ranks. */
+int rt_comm_create(const uint8_t* id128, int rank, int world, int device, rt_comm** out);
+/* All ranks in this process: out[i] = rank i on devices[i].  Distinct devices: an RCCL communicator.  One device listed
+ * n times: a REHEARSAL communicator (host barrier + a device add in rank order) for one-GPU boxes; anything else is refused. */
+int rt_comm_create_local(const int* devices, int n_devices, rt_comm** out);
+int rt_comm_rank(const rt_comm* comm);
+int rt_comm_world(const rt_comm* comm);
+/* buf (device memory on the rank's GPU, n floats): on return the root's buf holds the sum over all ranks, the other
+ * ranks' bufs are unchanged.  Collective: every rank calls it, each from its own host thread; returns when this rank's
+ * part has finished.  The caller's writes to buf must have completed (rt_render returns only then). */
+int rt_reduce(rt_comm* comm, float* buf, size_t n, int root);
+void rt_comm_destroy(rt_comm* comm);
+
+/* Device frames (the buffers rt_render(RT_RENDER_DEVICE_OUT) accumulates into and rt_reduce sums) for hosts that are not
+ * compiled with HIP: allocate on `device`, copy to host memory, clear, free. */
+int rt_buffer_alloc(int device, size_t bytes, void** out);
+int rt_buffer_download(int device, const void* src, void* host_dst, size_t bytes);
+int rt_buffer_zero(int device, void* p, size_t bytes);
+void rt_buffer_free(int device, void* p);
 
 #ifdef __cplusplus
 }

@@ -82,8 +82,10 @@ class RtError(RuntimeError):
 
 
 HIP_SYMBOLS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_create_instanced", "rt_scene_destroy",
-               "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_resolve",
-               "rt_scene_sync"]
+               "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_render_tiles",
+               "rt_resolve", "rt_scene_sync", "rt_comm_unique_id", "rt_comm_create", "rt_comm_create_local", "rt_comm_rank",
+               "rt_comm_world", "rt_reduce", "rt_comm_destroy", "rt_buffer_alloc", "rt_buffer_download", "rt_buffer_zero",
+               "rt_buffer_free"]
 NOALLOC_MAX_RAYS = 1 << 19
 
 
@@ -107,6 +109,15 @@ def load_libraries():
     hip.rt_trace_any.argtypes = [vp, vp, vp, i64, vp]
     hip.rt_trace_closest_noalloc.argtypes = [vp, vp, i64, vp]
     hip.rt_render.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtOptions), vp, C.POINTER(RtStats)]
+    hip.rt_render_tiles.argtypes = [vp, C.POINTER(RtCamera), C.POINTER(RtOptions), vp, i32, vp, C.POINTER(RtStats)]
+    hip.rt_comm_unique_id.argtypes = [vp]
+    hip.rt_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    hip.rt_comm_create_local.argtypes = [vp, i32, vp]
+    hip.rt_comm_rank.argtypes = [vp]
+    hip.rt_comm_world.argtypes = [vp]
+    hip.rt_reduce.argtypes = [vp, vp, C.c_size_t, i32]
+    hip.rt_comm_destroy.argtypes = [vp]
+    hip.rt_comm_destroy.restype = None
     hip.rt_resolve.argtypes = [vp, vp, i32, i32, i32, f32, vp]
     hip.rt_scene_sync.argtypes = [vp]
     host.rth_bvh_build.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -141,6 +152,10 @@ def load_libraries():
     host.rth_write_image.argtypes = [C.c_char_p, i32, i32, vp]
     host.rth_write_image.restype = i32
     host.rth_render_image.argtypes = [vp, vp, f32, i32, i32, i32, i32, C.c_uint32, C.c_char_p, vp, vp, C.POINTER(RtStats)]
+    host.rth_render_image_sharded.argtypes = [vp, vp, f32, i32, i32, i32, i32, C.c_uint32, vp, i32, i32, i32, vp, vp, C.POINTER(RtStats)]
+    host.rth_shard_sample_window.argtypes = [i32, i32, i32, vp]
+    host.rth_shard_tiles.argtypes = [i32, i32, i32, i32, i32, vp, i32]
+    host.rth_shard_tiles.restype = i32
     host.rth_scene_closest_hit.argtypes = [vp, vp, vp, vp, vp, vp]
     host.rth_scene_new_triangle_mesh.argtypes = [vp, vp, i64, vp, i64, i32]
     host.rth_scene_new_triangle_mesh.restype = i32
@@ -227,6 +242,24 @@ def camera_ray(view16, fov_deg, width, height, raster_x, raster_y):
     return out[0]
 
 
+def shard_sample_window(rank, world, spp):
+    """The host mirror's sample-pass partition: rank's (begin, count) window of the one spp-sample set."""
+    _, host = load_libraries()
+    out = np.zeros(2, np.int32)
+    host.rth_shard_sample_window(rank, world, spp, _ptr(out))
+    return int(out[0]), int(out[1])
+
+
+def shard_tiles(rank, world, width, height, tile=64):
+    """The host mirror's image-tile partition: interleaved tile x tile tiles, tile t -> rank t mod world; n x (x0, y0, x1, y1)."""
+    _, host = load_libraries()
+    n = host.rth_shard_tiles(rank, world, width, height, tile, None, 0)
+    out = np.zeros((max(n, 0), 4), np.int32)
+    if n > 0:
+        host.rth_shard_tiles(rank, world, width, height, tile, _ptr(out), n)
+    return out
+
+
 def bvh_build(bounds6, max_per_node=1, strategy=1):
     """BVH::build (BVH.cpp:131-149) on the host. strategy: 0 = BVH_MIDDLE, 1 = BVH_SAH."""
     _, host = load_libraries()
@@ -245,6 +278,53 @@ def material(type, c0=(0, 0, 0), c1=(0, 0, 0), s=()):
     m["c1"] = c1
     m["s"][0, : len(s)] = s
     return m
+
+
+class Comm:
+    """One rank of a frame-reduce communicator (rt_comm_*, include/rt_hip.h)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        load_libraries()
+        buf = np.zeros(128, np.uint8)
+        _check(_hip.rt_comm_unique_id(_ptr(buf)))
+        return buf
+
+    @staticmethod
+    def create(unique_id, rank, world, device):
+        load_libraries()
+        uid = np.ascontiguousarray(unique_id, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(_hip.rt_comm_create(_ptr(uid), rank, world, device, C.byref(h)))
+        return Comm(h)
+
+    @staticmethod
+    def create_local(devices):
+        load_libraries()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        out = (C.c_void_p * len(dev))()
+        _check(_hip.rt_comm_create_local(_ptr(dev), len(dev), out))
+        return [Comm(C.c_void_p(h)) for h in out]
+
+    @property
+    def rank(self):
+        return int(_hip.rt_comm_rank(self._h))
+
+    @property
+    def world(self):
+        return int(_hip.rt_comm_world(self._h))
+
+    def reduce(self, device_ptr, n, root=0):
+        """Sum of every rank's n-float device buffer into the root's (collective; blocks until this rank's part is done)."""
+        _check(_hip.rt_reduce(self._h, C.c_void_p(device_ptr), n, root))
+
+    def close(self):
+        if self._h:
+            _hip.rt_comm_destroy(self._h)
+            self._h = None
 
 
 class Scene:
@@ -437,8 +517,9 @@ class Scene:
         return occ
 
     def render(self, cam, width, height, spp, max_depth, seed=0, spp_begin=0, spp_total=None, tile=None,
-               spp_per_pass=0, out=None, device_out=None, timing=False, clear=None, serial=False):
-        """rt_render.  Returns (radiance_sum [H,W,3] fp32 or None with device_out, stats dict)."""
+               spp_per_pass=0, out=None, device_out=None, timing=False, clear=None, serial=False, tiles=None):
+        """rt_render, or rt_render_tiles when `tiles` (n x (x0, y0, x1, y1), disjoint) is given.
+        Returns (radiance_sum [H,W,3] fp32 or None with device_out, stats dict)."""
         opt = RtOptions()
         opt.width, opt.height = width, height
         opt.spp_begin, opt.spp_count = spp_begin, spp
@@ -449,12 +530,20 @@ class Scene:
         opt.spp_per_pass = spp_per_pass
         flags = (RENDER_TIMING if timing else 0) | (RENDER_SERIAL if serial else 0)
         stats = RtStats()
+        if tiles is not None:
+            tiles = np.ascontiguousarray(tiles, dtype=np.int32).reshape(-1, 4)
+
+        def call(target):
+            if tiles is None:
+                return _hip.rt_render(self.gpu, C.byref(cam), C.byref(opt), target, C.byref(stats))
+            return _hip.rt_render_tiles(self.gpu, C.byref(cam), C.byref(opt), _ptr(tiles), len(tiles), target, C.byref(stats))
+
         if device_out is not None:
             flags |= RENDER_DEVICE_OUT
             if clear:
                 flags |= RENDER_CLEAR
             opt.flags = flags
-            _check(_hip.rt_render(self.gpu, C.byref(cam), C.byref(opt), C.c_void_p(device_out), C.byref(stats)))
+            _check(call(C.c_void_p(device_out)))
             return None, stats.as_dict()
         if out is None:
             out = np.zeros((height, width, 3), np.float32)
@@ -462,7 +551,7 @@ class Scene:
         elif clear:
             flags |= RENDER_CLEAR
         opt.flags = flags
-        _check(_hip.rt_render(self.gpu, C.byref(cam), C.byref(opt), _ptr(out), C.byref(stats)))
+        _check(call(_ptr(out)))
         return out, stats.as_dict()
 
     def resolve(self, radiance_sum, spp, gamma=2.2):
@@ -481,6 +570,20 @@ class Scene:
                                          os.fsencode(bmp_path) if bmp_path else None, _ptr(rgb), _ptr(rad), C.byref(stats))
         if not ok:
             raise RtError("render_image failed: " + last_error())
+        return rgb, rad, stats.as_dict()
+
+    def render_image_sharded(self, view16, fov_deg, width, height, spp, max_depth, devices, sharding=0, tile_size=64, seed=0):
+        """Renderer::render_image with Options::devices = devices (one host thread and one scene replica per entry; a device
+        listed twice rehearses on one GPU), sharding 0 = sample windows of the one spp-sample set, 1 = interleaved tiles;
+        the frames meet in rt_reduce.  -> (u8 image, fp32 sums, stats)."""
+        rgb = np.zeros((height, width, 3), np.uint8)
+        rad = np.zeros((height, width, 3), np.float32)
+        stats = RtStats()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        ok = self._host.rth_render_image_sharded(self._h, _ptr(_f32(view16, 16)), fov_deg, width, height, spp, max_depth, seed, _ptr(dev),
+                                                 len(dev), int(sharding), int(tile_size), _ptr(rgb), _ptr(rad), C.byref(stats))
+        if not ok:
+            raise RtError("render_image_sharded failed: " + last_error())
         return rgb, rad, stats.as_dict()
 
     def closest_hit(self, ray):

@@ -41,6 +41,7 @@ static int fail(int code, const std::string& msg) {
     g_err_lit = nullptr;
     return code;
 }
+int rt_fail_message(int code, const std::string& msg) { return fail(code, msg); } // for rt_comm.hip (same library)
 static int fail_lit(int code, const char* literal) { // for the entry point that must not allocate (std::string may)
     g_err_lit = literal;
     return code;
@@ -102,13 +103,37 @@ struct PassParams {
     uint32_t shard_cap;       // ray-queue entries reserved per shard (multiple of RT_BLOCK)
     uint32_t capq;            // n_shards * shard_cap >= cap: range of queue indices
     int32_t has_env;
+    // rt_render_tiles: the call's pixels are those of n_tiles disjoint rectangles, numbered tile after tile (row-major
+    // within a tile); tile_tab[k] = (x0, y0, width, number of the tile's first pixel).  n_tiles == 0: the one rectangle above.
+    const int4* tile_tab;
+    int32_t n_tiles;
 };
+
+// pixel number within the call (0 .. npix) -> raster position
+RT_DEV void pixel_of(const PassParams& pp, int pix, int* x, int* y) {
+    if (pp.n_tiles == 0) {
+        *x = pp.x0 + pix % pp.tw;
+        *y = pp.y0 + pix / pp.tw;
+        return;
+    }
+    int lo = 0, hi = pp.n_tiles - 1;
+    while (lo < hi) { // the last tile whose first pixel is <= pix
+        const int mid = (lo + hi + 1) >> 1;
+        if (pp.tile_tab[mid].w <= pix) lo = mid;
+        else hi = mid - 1;
+    }
+    const int4 t = pp.tile_tab[lo];
+    const int local = pix - t.w;
+    *x = t.x + local % t.z;
+    *y = t.y + local / t.z;
+}
 
 __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     const int p = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (p >= pp.cap) return;
     const int s_local = p / pp.npix, pix = p - s_local * pp.npix;
-    const int x = pp.x0 + pix % pp.tw, y = pp.y0 + pix / pp.tw;
+    int x, y;
+    pixel_of(pp, pix, &x, &y);
     V3 o, d;
     camera_ray(pp.cam, x, y, (uint32_t)(pp.spp_first + s_local), pp.spp_total, &o, &d);
     w.q_o[0][p] = pack(o, __int_as_float(p));
@@ -581,7 +606,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(Wave w, PassParams pp, 
     const int pix = blockIdx.x * RT_BLOCK + threadIdx.x;
     for (int i = pix; i < RT_COUNTS; i += gridDim.x * RT_BLOCK) w.counts_dense[i] = w.counts[(size_t)i * RT_CSTRIDE];
     if (pix >= pp.npix) return;
-    const int x = pp.x0 + pix % pp.tw, y = pp.y0 + pix / pp.tw;
+    int x, y;
+    pixel_of(pp, pix, &x, &y);
     float* px = sum + ((size_t)y * pp.width + x) * 3;
     V3 total(px[0], px[1], px[2]);
     for (int s = 0; s < pp.spp_pass; s++) {
@@ -664,6 +690,12 @@ struct rt_scene {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     unsigned char* scratch_ptr = nullptr; // this GPU's copy of `scratch` (rt_trace_closest_noalloc)
+    // rt_render_tiles: device copy of the tile table and the host copy it was made from (an unchanged list is neither
+    // checked nor uploaded again)
+    int4* d_tiles = nullptr;
+    size_t d_tiles_cap = 0;
+    std::vector<int32_t> tiles_host; // x0, y0, x1, y1 per tile, as the caller gave them
+    int64_t tiles_npix = 0;
 };
 
 template <typename T>
@@ -1059,6 +1091,7 @@ void rt_scene_destroy(rt_scene* s) {
     free_wave(s);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->d_sum) (void)hipFree(s->d_sum);
+    if (s->d_tiles) (void)hipFree(s->d_tiles);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -1220,17 +1253,62 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit*
     return RT_OK;
 }
 
-int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* radiance_sum, rt_stats* stats) {
+// Checks a tile list (rectangles inside the raster, not empty, pairwise disjoint) and puts its device table in place.
+static int set_tiles(rt_scene* s, const rt_options* o, const int32_t* tiles, int32_t n_tiles) {
+    if (s->tiles_host.size() == (size_t)4 * n_tiles && std::memcmp(s->tiles_host.data(), tiles, sizeof(int32_t) * 4 * (size_t)n_tiles) == 0 && s->d_tiles)
+        return RT_OK; // the list of the previous call
+    std::vector<int4> tab((size_t)n_tiles);
+    int64_t first = 0;
+    for (int32_t k = 0; k < n_tiles; k++) {
+        const int32_t x0 = tiles[4 * k], y0 = tiles[4 * k + 1], x1 = tiles[4 * k + 2], y1 = tiles[4 * k + 3];
+        if (x0 < 0 || y0 < 0 || x1 > o->width || y1 > o->height || x0 >= x1 || y0 >= y1) return fail(RT_ERR_INVALID, "rt_render_tiles: bad tile rectangle");
+        tab[(size_t)k] = make_int4(x0, y0, x1 - x0, (int)first);
+        first += (int64_t)(x1 - x0) * (y1 - y0);
+        if (first > 0x7fffffff) return fail(RT_ERR_LIMIT, "rt_render_tiles: more than 2^31-1 pixels");
+    }
+    // two lanes adding to one pixel would race: overlapping tiles are refused (sorted by row, compared within a row band)
+    std::vector<int32_t> order((size_t)n_tiles);
+    for (int32_t k = 0; k < n_tiles; k++) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return tiles[4 * a + 1] < tiles[4 * b + 1]; });
+    for (int32_t i = 0; i < n_tiles; i++) {
+        const int32_t* a = tiles + 4 * order[(size_t)i];
+        for (int32_t j = i + 1; j < n_tiles; j++) {
+            const int32_t* b = tiles + 4 * order[(size_t)j];
+            if (b[1] >= a[3]) break; // starts below a's last row, and so do all later ones
+            if (b[0] < a[2] && a[0] < b[2]) return fail(RT_ERR_INVALID, "rt_render_tiles: tiles overlap");
+        }
+    }
+    if (s->d_tiles_cap < (size_t)n_tiles) {
+        if (s->d_tiles) (void)hipFree(s->d_tiles);
+        s->d_tiles = nullptr;
+        s->d_tiles_cap = 0;
+        HIPCHK(hipMalloc((void**)&s->d_tiles, sizeof(int4) * (size_t)n_tiles));
+        s->d_tiles_cap = (size_t)n_tiles;
+    }
+    s->tiles_host.clear();
+    HIPCHK(hipMemcpy(s->d_tiles, tab.data(), sizeof(int4) * (size_t)n_tiles, hipMemcpyHostToDevice));
+    s->tiles_host.assign(tiles, tiles + 4 * (size_t)n_tiles);
+    s->tiles_npix = first;
+    return RT_OK;
+}
+
+static int render_common(rt_scene* s, const rt_camera* cam, const rt_options* o, const int32_t* tiles, int32_t n_tiles, float* radiance_sum,
+                         rt_stats* stats) {
     if (!s || !cam || !o || !radiance_sum) return fail(RT_ERR_INVALID, "rt_render: null argument");
-    if (o->width <= 0 || o->height <= 0 || o->x0 < 0 || o->y0 < 0 || o->x1 > o->width || o->y1 > o->height || o->x0 >= o->x1 || o->y0 >= o->y1)
+    if (o->width <= 0 || o->height <= 0) return fail(RT_ERR_INVALID, "rt_render: bad raster size");
+    if (n_tiles == 0 && (o->x0 < 0 || o->y0 < 0 || o->x1 > o->width || o->y1 > o->height || o->x0 >= o->x1 || o->y0 >= o->y1))
         return fail(RT_ERR_INVALID, "rt_render: bad tile rectangle");
     if (o->spp_count <= 0 || o->spp_begin < 0 || o->spp_total < o->spp_begin + o->spp_count)
         return fail(RT_ERR_INVALID, "rt_render: bad sample window");
     if (o->max_depth < 1 || o->max_depth > 63) return fail(RT_ERR_LIMIT, "rt_render: max_depth must be in [1, 63]");
     HIPCHK(hipSetDevice(s->device));
+    if (n_tiles > 0) {
+        const int rc_tiles = set_tiles(s, o, tiles, n_tiles);
+        if (rc_tiles) return rc_tiles;
+    }
 
-    const int tw = o->x1 - o->x0, th = o->y1 - o->y0;
-    const int64_t npix = (int64_t)tw * th;
+    const int tw = n_tiles ? 0 : o->x1 - o->x0, th = n_tiles ? 0 : o->y1 - o->y0;
+    const int64_t npix = n_tiles ? s->tiles_npix : (int64_t)tw * th;
     int spp_pass = o->spp_per_pass;
     // auto: as many passes as can be in flight (max_sets), each up to 16 Mi paths (measured at 1080p, 32 spp per call:
     // 8 spp per pass 6.6 Grays/s, 4 spp 6.5, 2 spp 6.2; two passes of 8 spp in a 16-spp call only 5.7)
@@ -1319,6 +1397,8 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         pp.cap = (int32_t)(npix * pp.spp_pass);
         pp.K = K;
         pp.has_env = has_env ? 1 : 0;
+        pp.tile_tab = n_tiles ? s->d_tiles : nullptr;
+        pp.n_tiles = n_tiles;
         // queue geometry is that of the call's largest pass, so NEE slot strides stay valid for a short last pass
         pp.n_shards = RT_SHARDS;
         pp.shard_cap = (uint32_t)shard_cap;
@@ -1422,6 +1502,17 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* rad
         stats->ms_accumulate += st.ms_accumulate;
     }
     return RT_OK;
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, const rt_options* o, float* radiance_sum, rt_stats* stats) {
+    return render_common(s, cam, o, nullptr, 0, radiance_sum, stats);
+}
+
+int rt_render_tiles(rt_scene* s, const rt_camera* cam, const rt_options* o, const int32_t* tiles_xyxy, int32_t n_tiles, float* radiance_sum,
+                    rt_stats* stats) {
+    if (!tiles_xyxy || n_tiles <= 0) return fail(RT_ERR_INVALID, "rt_render_tiles: empty tile list");
+    if (n_tiles > (1 << 20)) return fail(RT_ERR_LIMIT, "rt_render_tiles: more than 2^20 tiles");
+    return render_common(s, cam, o, tiles_xyxy, n_tiles, radiance_sum, stats);
 }
 
 #ifdef RT_STATS

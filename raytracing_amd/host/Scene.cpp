@@ -6,6 +6,7 @@
 #include <cstring>
 #include <map>
 #include <set>
+#include <thread>
 
 namespace rt {
 
@@ -202,6 +203,7 @@ void TriangleMesh::describe(rt_instance* o) const { o->geometry = RT_GEO_MESH; }
 // ------------------------------------------------------------------ Scene
 Scene::~Scene() {
     if (gpu_scene) rt_scene_destroy(gpu_scene);
+    for (auto& r : replicas) rt_scene_destroy(r.second);
     // instances may share a geometry (one TriangleMesh placed many times) and their materials are also in `materials`
     std::set<const void*> freed;
     auto once = [&](auto* p) {
@@ -520,6 +522,28 @@ bool Scene::upload(int dev) {
         rt_scene_destroy(gpu_scene);
         gpu_scene = nullptr;
     }
+    device = dev;
+    gpu_scene = create_on(dev);
+    return gpu_scene != nullptr;
+}
+
+bool Scene::upload_replicas(const std::vector<int>& devices) {
+    for (auto& r : replicas) rt_scene_destroy(r.second);
+    replicas.clear();
+    for (int dev : devices) {
+        rt_scene* g = create_on(dev);
+        if (!g) {
+            for (auto& r : replicas) rt_scene_destroy(r.second);
+            replicas.clear();
+            return false;
+        }
+        replicas.push_back({dev, g});
+    }
+    return true;
+}
+
+rt_scene* Scene::create_on(int dev) const {
+    rt_scene* made = nullptr;
     const FlatScene& f = flat_scene;
     rt_scene_desc d{};
     d.root_ref = f.root_ref;
@@ -546,19 +570,17 @@ bool Scene::upload(int dev) {
         d.env_total = f.env_total;
         d.env_offset = environment_offset;
     }
-    device = dev;
     rt_tlas_desc tl{};
     tl.root_ref = f.tlas_root_ref;
     tl.n_pairs = (int64_t)f.tlas_pairs.size();
     tl.pairs = f.tlas_pairs.data();
     tl.n_instances = (int32_t)f.instances.size();
     tl.instances = f.instances.data();
-    if ((f.instances.empty() ? rt_scene_create(&d, dev, &gpu_scene) : rt_scene_create_instanced(&d, &tl, dev, &gpu_scene)) != RT_OK) {
+    if ((f.instances.empty() ? rt_scene_create(&d, dev, &made) : rt_scene_create_instanced(&d, &tl, dev, &made)) != RT_OK) {
         std::printf("Scene upload failed: %s\n", rt_last_error());
-        gpu_scene = nullptr;
-        return false;
+        return nullptr;
     }
-    return true;
+    return made;
 }
 
 void Scene::build_top_level_bvh() {
@@ -664,8 +686,133 @@ void Renderer::initalize(const Options& options) { // main.cpp:936-948
     radiance_sum.assign((size_t)width * height * 3, 0.f);
 }
 
+void shard_sample_window(int rank, int world, int spp, int* begin, int* count) {
+    const int base = spp / world, extra = spp % world; // the first `extra` ranks take one sample more
+    *begin = rank * base + (rank < extra ? rank : extra);
+    *count = base + (rank < extra ? 1 : 0);
+}
+
+std::vector<int32_t> shard_tiles(int rank, int world, int width, int height, int tile) {
+    std::vector<int32_t> out;
+    const int tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile;
+    for (int t = rank; t < tx * ty; t += world) { // row-major tile index, as TileQueue counts (main.cpp:914-928)
+        const int x0 = (t % tx) * tile, y0 = (t / tx) * tile;
+        out.insert(out.end(), {x0, y0, std::min(x0 + tile, width), std::min(y0 + tile, height)});
+    }
+    return out;
+}
+
+// Options::devices names G GPUs: one host thread per GPU renders its share into a frame in that GPU's memory (no data-path
+// collective), rt_reduce sums the frames into rank 0's, rank 0 resolves.  Where the reference starts hardware_concurrency()
+// threads that pull 16x16 tiles (main.cpp:954-1005), this starts G threads that each own a GPU.
+bool Renderer::render_sharded(const Camera& cam, const Scene& scene, const Options& options) {
+    const int G = (int)options.devices.size();
+    if ((int)scene.replica_count() != G) {
+        std::printf("Renderer: Scene::upload_replicas(options.devices) must have placed the scene on the %d devices first\n", G);
+        return false;
+    }
+    for (int r = 0; r < G; r++)
+        if (scene.replica_device((size_t)r) != options.devices[(size_t)r]) {
+            std::printf("Renderer: replica %d is on device %d, Options::devices says %d\n", r, scene.replica_device((size_t)r), options.devices[(size_t)r]);
+            return false;
+        }
+    if (options.sharding == Options::SHARD_SAMPLES && samples < G) {
+        std::printf("Renderer: %d samples per pixel cannot be split over %d GPUs\n", samples, G);
+        return false;
+    }
+    std::vector<rt_comm*> comms((size_t)G, nullptr);
+    if (rt_comm_create_local(options.devices.data(), G, comms.data()) != RT_OK) {
+        std::printf("Renderer: %s\n", rt_last_error());
+        return false;
+    }
+    const size_t n = (size_t)width * height * 3;
+    std::vector<void*> frames((size_t)G, nullptr);
+    std::vector<rt_stats> stats((size_t)G);
+    std::vector<std::string> errors((size_t)G);
+    const rt_camera c = cam.flatten();
+    auto rank_main = [&](int r) {
+        auto failed = [&]() { errors[(size_t)r] = rt_last_error(); };
+        if (rt_buffer_alloc(options.devices[(size_t)r], n * sizeof(float), &frames[(size_t)r]) != RT_OK) return failed();
+        rt_options o{};
+        o.width = width;
+        o.height = height;
+        o.spp_total = samples;
+        o.max_depth = options.max_depth;
+        o.x0 = 0;
+        o.y0 = 0;
+        o.x1 = width;
+        o.y1 = height;
+        o.seed = options.seed;
+        o.spp_per_pass = options.spp_per_pass;
+        o.flags = RT_RENDER_CLEAR | RT_RENDER_DEVICE_OUT;
+        stats[(size_t)r] = rt_stats{};
+        int rc;
+        if (options.sharding == Options::SHARD_TILES) {
+            o.spp_begin = 0;
+            o.spp_count = samples;
+            const std::vector<int32_t> tiles = shard_tiles(r, G, width, height, options.gpu_tile_size > 0 ? options.gpu_tile_size : 64);
+            if (tiles.empty()) { // more ranks than tiles: this rank contributes a zero frame
+                rc = rt_buffer_zero(options.devices[(size_t)r], frames[(size_t)r], n * sizeof(float));
+            } else {
+                rc = rt_render_tiles(scene.replica((size_t)r), &c, &o, tiles.data(), (int32_t)(tiles.size() / 4), (float*)frames[(size_t)r], &stats[(size_t)r]);
+            }
+        } else {
+            int begin, count;
+            shard_sample_window(r, G, samples, &begin, &count);
+            o.spp_begin = begin;
+            o.spp_count = count;
+            rc = rt_render(scene.replica((size_t)r), &c, &o, (float*)frames[(size_t)r], &stats[(size_t)r]);
+        }
+        if (rc != RT_OK) failed();
+        // every rank enters the collective, also one whose render failed (its frame then holds what it holds; the error is reported)
+        if (rt_reduce(comms[(size_t)r], (float*)frames[(size_t)r], n, 0) != RT_OK && errors[(size_t)r].empty()) failed();
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < G; r++) threads.emplace_back(rank_main, r);
+    rank_main(0);
+    for (std::thread& t : threads) t.join();
+    bool ok = true;
+    for (int r = 0; r < G; r++)
+        if (!errors[(size_t)r].empty()) {
+            std::printf("Renderer: rank %d (device %d): %s\n", r, options.devices[(size_t)r], errors[(size_t)r].c_str());
+            ok = false;
+        }
+    if (ok && rt_buffer_download(options.devices[0], frames[0], radiance_sum.data(), n * sizeof(float)) != RT_OK) {
+        std::printf("Renderer: %s\n", rt_last_error());
+        ok = false;
+    }
+    for (int r = 0; r < G; r++) {
+        rt_buffer_free(options.devices[(size_t)r], frames[(size_t)r]);
+        rt_comm_destroy(comms[(size_t)r]);
+    }
+    last_stats = rt_stats{};
+    for (const rt_stats& st : stats) { // work adds up over the GPUs, time is the slowest GPU's
+        last_stats.rays_closest += st.rays_closest;
+        last_stats.rays_shadow += st.rays_shadow;
+        last_stats.paths += st.paths;
+        last_stats.launches_closest += st.launches_closest;
+        last_stats.launches_shadow += st.launches_shadow;
+        last_stats.ms_total = std::max(last_stats.ms_total, st.ms_total);
+    }
+    return ok;
+}
+
 void Renderer::render_image(const Camera& cam, const Scene& scene, const Options& options) { // main.cpp:950-1020
     initalize(options);
+    if (options.devices.size() > 1) {
+        if (!render_sharded(cam, scene, options)) {
+            last_stats = rt_stats{};
+            return;
+        }
+        if (rt_resolve(scene.replica(0), radiance_sum.data(), width, height, samples, options.gamma, final_buffer.data()) != RT_OK) {
+            std::printf("Renderer: %s\n", rt_last_error());
+            return;
+        }
+        std::printf("\nDONE, seconds elapsed: %g\n", last_stats.ms_total / 1000.0);
+        if (write_output && write_image(options.output_name, width, height, final_buffer.data()))
+            std::printf("Output written: %s\n", options.output_name.c_str());
+        return;
+    }
     if (!scene.gpu()) {
         std::printf("Renderer: scene is not on a GPU (call build_top_level_bvh first)\n");
         return;

@@ -216,6 +216,12 @@ public:
     void flatten();
     bool upload(int device);
     rt_scene* gpu() const { return gpu_scene; }
+    // Multi-GPU: one copy of the flattened scene per listed device (a device may be listed twice: rehearsal on one GPU).
+    // Renderer::render_image uses replica i as rank i when Options::devices names the same list.
+    bool upload_replicas(const std::vector<int>& devices);
+    size_t replica_count() const { return replicas.size(); }
+    rt_scene* replica(size_t i) const { return replicas[i].second; }
+    int replica_device(size_t i) const { return replicas[i].first; }
     const FlatScene& flat() const { return flat_scene; }
 
     bool hasCamera = false;
@@ -244,6 +250,8 @@ public:
 private:
     FlatScene flat_scene;
     rt_scene* gpu_scene = nullptr;
+    std::vector<std::pair<int, rt_scene*>> replicas;
+    rt_scene* create_on(int dev) const;
     std::vector<int> light_first_tri; // per rect light: first of its two triangles
     void flatten_two_level();
 };
@@ -259,7 +267,17 @@ struct Options { // main.cpp:836-850
     float gamma = 2.2f;
     unsigned seed = 0;
     int spp_per_pass = 0;
+    // Multi-GPU (SURVEY 8 e; no counterpart in the reference, whose parallelism is std::thread over 16x16 tiles): the GPUs to
+    // render on, one host thread each; how the frame is cut; the GPU tile edge.  Empty devices = the scene's own GPU.
+    std::vector<int> devices;
+    enum Sharding { SHARD_SAMPLES = 0, SHARD_TILES = 1 };
+    int sharding = SHARD_SAMPLES; // SAMPLES: rank r renders its window of the ONE spp-sample set; TILES: interleaved tiles, t -> rank t mod G
+    int gpu_tile_size = 64;
 };
+
+// The two partitions of a frame over G ranks (also what bench.py and raytracing_amd/sharding.py compute).
+void shard_sample_window(int rank, int world, int spp, int* begin, int* count); // disjoint windows covering [0, spp)
+std::vector<int32_t> shard_tiles(int rank, int world, int width, int height, int tile); // x0,y0,x1,y1 per tile, tile t -> rank t % world
 
 class Renderer { // main.cpp:853-903,950-1020
 public:
@@ -274,6 +292,7 @@ public:
     bool write_output = true;
 
 private:
+    bool render_sharded(const Camera& cam, const Scene& scene, const Options& options);
     int width = 0, height = 0, samples = 0;
     std::vector<uint8_t> final_buffer;
     std::vector<float> radiance_sum;

@@ -322,6 +322,43 @@ int32_t rth_render_image(rth_scene* s, const float* view16, float fov, int32_t w
     return 1;
 }
 
+// Renderer::render_image over several GPUs (Options::devices; sharding 0 = sample windows, 1 = interleaved tiles): the scene
+// is placed on the listed devices first (Scene::upload_replicas).
+int32_t rth_render_image_sharded(rth_scene* s, const float* view16, float fov, int32_t w, int32_t h, int32_t spp, int32_t max_depth,
+                                 uint32_t seed, const int32_t* devices, int32_t n_devices, int32_t sharding, int32_t tile_size,
+                                 uint8_t* rgb_out, float* radiance_out, rt_stats* stats) {
+    Camera cam(mat4::from_columns(view16), fov, w, h);
+    Options o;
+    o.width = w;
+    o.height = h;
+    o.samples_per_pixel = spp;
+    o.max_depth = max_depth;
+    o.seed = seed;
+    o.devices.assign(devices, devices + n_devices);
+    o.sharding = sharding;
+    if (tile_size > 0) o.gpu_tile_size = tile_size;
+    if (!s->scene.upload_replicas(o.devices)) return 0;
+    Renderer r;
+    r.write_output = false;
+    r.render_image(cam, s->scene, o);
+    if (r.last_stats.paths == 0) return 0;
+    if (rgb_out) std::memcpy(rgb_out, r.pixels().data(), r.pixels().size());
+    if (radiance_out) std::memcpy(radiance_out, r.radiance().data(), r.radiance().size() * sizeof(float));
+    if (stats) *stats = r.last_stats;
+    return 1;
+}
+
+// the two partitions (Scene.h): for scripts that shard by process (bench.py) and for the tests
+void rth_shard_sample_window(int32_t rank, int32_t world, int32_t spp, int32_t* begin_count2) {
+    shard_sample_window(rank, world, spp, &begin_count2[0], &begin_count2[1]);
+}
+int32_t rth_shard_tiles(int32_t rank, int32_t world, int32_t width, int32_t height, int32_t tile, int32_t* out_xyxy, int32_t capacity_tiles) {
+    const std::vector<int32_t> t = shard_tiles(rank, world, width, height, tile);
+    const int32_t n = (int32_t)(t.size() / 4);
+    if (out_xyxy && n <= capacity_tiles) std::memcpy(out_xyxy, t.data(), t.size() * sizeof(int32_t));
+    return n;
+}
+
 // Scene::closest_hit / Scene::any_hit for one ray (host API smoke).
 int32_t rth_scene_closest_hit(rth_scene* s, const rt_ray* ray, float* t, float* point3, float* normal3, int32_t* front_face) {
     Intersection si;

@@ -10,24 +10,32 @@ the scene is replicated and the loop is split with NO data-path collective:
 
 
 def sample_window(rank, world, spp_per_rank):
-    """-> (spp_begin, spp_count, spp_total) for rt_render on this rank."""
+    """Weak scaling (every rank renders spp_per_rank samples of a world * spp_per_rank set):
+    -> (spp_begin, spp_count, spp_total) for rt_render on this rank."""
     if not (0 <= rank < world) or spp_per_rank <= 0:
         raise ValueError("bad rank/world/spp")
     return rank * spp_per_rank, spp_per_rank, world * spp_per_rank
 
 
+def strong_sample_window(rank, world, spp_total):
+    """Strong scaling (the frame's spp_total samples are FIXED and cut into `world` windows; the partition is the C++ host
+    mirror's, rt::shard_sample_window): -> (spp_begin, spp_count, spp_total)."""
+    import raytracing_amd as rta
+
+    if not (0 <= rank < world) or spp_total < world:
+        raise ValueError("bad rank/world/spp")
+    begin, count = rta.shard_sample_window(rank, world, spp_total)
+    return begin, count, spp_total
+
+
 def tiles_for_rank(width, height, rank, world, extent=64):
-    """Row-major extent x extent tiles (TileQueue::next_tile order), tile t owned by rank t % world.
-    -> list of (x0, y0, x1, y1)."""
+    """Row-major extent x extent tiles (TileQueue::next_tile order), tile t owned by rank t % world (the C++ host mirror's
+    rt::shard_tiles).  -> list of (x0, y0, x1, y1)."""
+    import raytracing_amd as rta
+
     if not (0 <= rank < world) or extent <= 0:
         raise ValueError("bad rank/world/extent")
-    tw = (width + extent - 1) // extent
-    th = (height + extent - 1) // extent
-    out = []
-    for t in range(rank, tw * th, world):
-        x0, y0 = (t % tw) * extent, (t // tw) * extent
-        out.append((x0, y0, min(x0 + extent, width), min(y0 + extent, height)))
-    return out
+    return [tuple(int(v) for v in t) for t in rta.shard_tiles(rank, world, width, height, extent)]
 
 
 def reduce_frame(frame, dst=0):
