@@ -25,9 +25,7 @@
 // node visits fall into the first 64 records.  Two 1024-thread workgroups fill a CU (32 waves) and each stages ONE copy
 // of the top for its 16 waves: measured 256 threads + 64 records 5.00, 512 + 128 5.07, 1024 + 256 5.15 Grays/s
 // (512 or 768 records: no further gain).
-#ifndef RT_OCC_TOP_PAIRS
-#define RT_OCC_TOP_PAIRS RT_TOP_PAIRS // tree top of the occlusion kernels
-#endif
+#define RT_OCC_TOP_PAIRS RT_TOP_PAIRS // tree top of the occlusion kernels (one layout for all walks: load_pair)
 #ifndef RT_SHORT_STACK
 #define RT_SHORT_STACK 8
 #endif
@@ -192,13 +190,19 @@ RT_DEV void slab_pair(const f4& q0, const f4& q1, const f4& q2, const RaySlab& r
 
 // One record: the top of the tree (every ray walks it) comes from LDS, which has its own bandwidth beside the vector
 // L1 that the divergent 64-byte record reads saturate; the rest through the 32-bit-offset form of the global load.
+// The LDS copy is kept as FOUR ARRAYS (all q0, all q1, all q2, all ref pairs), not as records: 64 lanes reading the same
+// 16-byte part of 64 unrelated 64-byte records touch only banks 16 r .. 16 r + 3 (a quarter of the banks); part arrays
+// spread the same reads over all of them.  Array strides are compile-time, so the three reads differ by an immediate.
+#define RT_TOP_Q_BYTES (RT_TOP_PAIRS * 16)
+#define RT_TOP_LDS_BYTES (RT_TOP_PAIRS * 56) // three float4 arrays + one array of (lref, rref)
 RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_bytes, int cur, f4& q0, f4& q1, f4& q2, int& lref, int& rref) {
     if (cur < top_bytes) {
-        lds_cf4* p = (lds_cf4*)((const __attribute__((address_space(3))) char*)top + cur);
-        q0 = p[0];
-        q1 = p[1];
-        q2 = p[2];
-        const unsigned long long rr = *(const __attribute__((address_space(3))) unsigned long long*)(p + 3); // ONE 8-byte read
+        const __attribute__((address_space(3))) char* base = (const __attribute__((address_space(3))) char*)top;
+        const uint32_t at = (uint32_t)cur >> 2; // record index * 16
+        q0 = *(lds_cf4*)(base + at);
+        q1 = *(lds_cf4*)(base + at + RT_TOP_Q_BYTES);
+        q2 = *(lds_cf4*)(base + at + 2 * RT_TOP_Q_BYTES);
+        const unsigned long long rr = *(const __attribute__((address_space(3))) unsigned long long*)(base + ((uint32_t)cur >> 3) + 3 * RT_TOP_Q_BYTES);
         lref = (int)(uint32_t)rr;
         rref = (int)(uint32_t)(rr >> 32);
     } else {

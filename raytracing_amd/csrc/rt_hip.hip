@@ -19,6 +19,7 @@
 #include "rt_device.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -147,11 +148,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     }
 }
 
-// Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup) and returns how many bytes that is.
-template <int TOP>
+// Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup), as the four part arrays load_pair reads,
+// and returns how many bytes of the pair array that covers.
 RT_DEV int stage_tree_top(const SceneView& sc, float4* s_top) {
-    const int n_top = sc.n_pairs < TOP ? sc.n_pairs : TOP;
-    for (int i = threadIdx.x; i < 4 * n_top; i += RT_TRAV_BLOCK) s_top[i] = sc.pairs[i];
+    const int n_top = sc.n_pairs < RT_TOP_PAIRS ? sc.n_pairs : RT_TOP_PAIRS;
+    for (int i = threadIdx.x; i < 4 * n_top; i += RT_TRAV_BLOCK) {
+        const int rec = i >> 2, part = i & 3;
+        const float4 v = sc.pairs[i];
+        if (part < 3) s_top[part * RT_TOP_PAIRS + rec] = v;
+        else ((float2*)(s_top + 3 * RT_TOP_PAIRS))[rec] = make_float2(v.x, v.y);
+    }
     __syncthreads();
     return n_top * RT_PAIR_BYTES;
 }
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_closest(SceneView sc, const f
                                                       const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
                                                       uint32_t n_shards, uint32_t shard_cap, float4* __restrict__ hit, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top<RT_TOP_PAIRS>(sc, s_top);
+    __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
+    const int top_bytes = stage_tree_top(sc, s_top);
     trace_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes, [&](const RayState& r) {
         int slot = r.slot;
         if (want_tri_id && slot >= 0) slot = (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END);
@@ -174,8 +180,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_shadow(SceneView sc, const fl
                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
                                                      uint32_t n_shards, uint32_t shard_cap, uint8_t* __restrict__ vis) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
+    __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
+    const int top_bytes = stage_tree_top(sc, s_top);
     occlusion_queue(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
                     [&](uint32_t q, uint32_t, bool occluded) { vis[q] = occluded ? 0 : 1; });
 }
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float
                                                   const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                   uint32_t shard_cap, uint8_t* __restrict__ occ) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_OCC_TOP_PAIRS > 0 ? RT_OCC_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top<RT_OCC_TOP_PAIRS>(sc, s_top);
+    __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
+    const int top_bytes = stage_tree_top(sc, s_top);
     occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
                     [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
@@ -203,8 +209,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK, RT_TL_WAVES) void k_closest2(SceneVi
                                                        const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                        uint32_t shard_cap, float4* __restrict__ hit, float4* __restrict__ hit2, int want_tri_id) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top<RT_TOP_PAIRS>(sc, s_top);
+    __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
+    const int top_bytes = stage_tree_top(sc, s_top);
     trace_queue2<false>(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
                         [&](uint32_t q, const Hit2& h, bool) {
                             int slot = h.slot;
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK, RT_TL_WAVES) void k_shadow2(SceneVie
                                                       const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
                                                       uint32_t shard_cap, uint8_t* __restrict__ out, int on_hit) {
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
-    __shared__ float4 s_top[(RT_TOP_PAIRS > 0 ? RT_TOP_PAIRS : 1) * 4];
-    const int top_bytes = stage_tree_top<RT_TOP_PAIRS>(sc, s_top);
+    __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
+    const int top_bytes = stage_tree_top(sc, s_top);
     trace_queue2<true>(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
                        [&](uint32_t q, const Hit2&, bool occluded) { out[q] = (uint8_t)(occluded ? on_hit : 1 - on_hit); });
 }
@@ -297,7 +303,17 @@ RT_DEV int classify_key(const SceneView& sc, const Wave& w, uint32_t q) {
     if (sc.inst_q) return slot == -1 ? RT_KEY_MISS : (int)sc.inst_type[__float_as_int(w.hit2[q].w) & (RT_HIT2_FRONT - 1)];
     return slot < 0 ? RT_KEY_MISS : (int)sc.tri_type[slot];
 }
+// Wave priority of the memory-bound kernels (shading, classify, resolve): when they share a CU with the ALU-bound walks of
+// another pass in flight, their few instructions between long memory waits should not queue behind the walks' arithmetic.
+#ifndef RT_SHADE_PRIO
+#define RT_SHADE_PRIO 3
+#endif
+RT_DEV void memory_bound_priority() {
+    if (RT_SHADE_PRIO > 0) __builtin_amdgcn_s_setprio(RT_SHADE_PRIO);
+}
+
 __global__ __launch_bounds__(RT_BLOCK) void k_classify(SceneView sc, Wave w, PassParams pp, int bounce) {
+    memory_bound_priority();
     __shared__ uint32_t s_tot[16]; // entries of this workgroup per key, then the next free index in the key's list
     const uint32_t lane = __lane_id();
     const uint32_t shard = blockIdx.x % pp.n_shards, sub = blockIdx.x / pp.n_shards, n_sub = gridDim.x / pp.n_shards;
@@ -531,6 +547,7 @@ __global__ __launch_bounds__(RT_BLOCK, TL ? RT_SHADE_WAVES_TL : RT_SHADE_WAVES) 
     __shared__ float s_env_cdf[RT_LDS_ENV];
     __shared__ float s_env_rgb[RT_LDS_ENV * 3];
     __shared__ float s_emissive[RT_LDS_CDF * 2];
+    memory_bound_priority();
     const uint32_t n = w.type_counts[(size_t)(bounce * 16 + KEY) * RT_CSTRIDE];
     if (blockIdx.x * RT_BLOCK >= n) return; // uniform: fewer entries than resident workgroups
     const SceneView& sc = sc_in;
@@ -579,6 +596,7 @@ __global__ __launch_bounds__(RT_BLOCK, TL ? RT_SHADE_WAVES_TL : RT_SHADE_WAVES) 
 // radiance += throughput * direct (main.cpp:430), a path's slots summed in reference order (environment ray, then the
 // lights).  One lane per shadow-queue entry; the lane of a path's FIRST ray does the path's sum (its rays are consecutive).
 __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp, int bounce) {
+    memory_bound_priority();
     const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t shard_span = (uint32_t)pp.K * pp.shard_cap; // shadow-queue entries reserved per shard
     const uint32_t shard = j / shard_span;
@@ -1374,6 +1392,7 @@ static int render_common(rt_scene* s, const rt_camera* cam, const rt_options* o,
     };
 
     uint32_t* h_counts = s->h_counts;
+    const auto host_t0 = std::chrono::steady_clock::now();
     HIPCHK(hipEventRecord(s->ev_begin, s->stream));
     if (sets > 1) { // the other streams start once the frame buffer is ready
         HIPCHK(hipEventRecord(s->ev_fork, s->stream));
@@ -1449,7 +1468,12 @@ static int render_common(rt_scene* s, const rt_camera* cam, const rt_options* o,
     if (sets > 1) HIPCHK(hipStreamWaitEvent(s->stream, s->ev_acc[(n_pass - 1) % sets], 0)); // join: it waited for all earlier ones
     HIPCHK(hipEventRecord(s->ev_end, s->stream));
     if (!dev_out) HIPCHK(hipMemcpyAsync(radiance_sum, d_sum, sum_n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    const auto host_t1 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(s->stream));
+    if (getenv("RT_TUNE_VERBOSE"))
+        std::fprintf(stderr, "rt_render: %d passes on %d streams enqueued in %.3f ms, finished %.3f ms after the first launch\n", n_pass, sets,
+                     std::chrono::duration<double, std::milli>(host_t1 - host_t0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count());
     for (int i = 1; i < sets; i++) HIPCHK(hipStreamSynchronize(s->streams[i])); // their counter read-backs
 
     if (stats) {
