@@ -857,7 +857,8 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
         if (!tl) {
             const int depth = pair_tree_depth(d->pairs, d->n_pairs, d->root_ref, seen);
             if (depth < 0) return fail(RT_ERR_INVALID, "rt_scene_create: the pair records do not form a tree (a record is reached twice)");
-            if (depth > RT_STACK_TOTAL) return fail(RT_ERR_LIMIT, "rt_scene_create: BVH deeper than 64 levels (the traversal stack of Object.h:275)");
+            if (depth > RT_STACK_TOTAL)
+                return fail(RT_ERR_LIMIT, "rt_scene_create: BVH deeper than 64 levels (" + std::to_string(depth) + "; the traversal stack of Object.h:275 holds 64 entries)");
         } else {
             std::vector<int32_t> roots;
             for (int32_t i = 0; i < tl->n_instances && tl->instances; i++)

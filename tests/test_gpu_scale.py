@@ -110,12 +110,16 @@ def test_cornell_with_instances_bit_parity(rta, orc, gpu):
 
 
 def test_instanced_5m_properties(rta, gpu):
-    """The configuration's full size: 100 352-triangle mesh x 50 instances + cornellbox = 5.03 M triangles (BVH_MIDDLE
-    tree), checked through occlusion <=> closest hit and batch-order independence."""
+    """The configuration's full size: 100 352-triangle mesh x 50 instances + cornellbox = 5.03 M triangles, checked through
+    occlusion <=> closest hit and batch-order independence.  (SAH tree: the BVH_MIDDLE tree of this scene is deeper than the 64
+    entries of the reference's traversal stack, Object.h:275, and rt_scene_create refuses such a tree.)"""
     sc = scenes.cornell_with_instances(rta, 225, 224, 50)
     n = len(sc.array(rta.ARR_TRIS))
     assert n == 13170 + 50 * 2 * 224 * 224
     sc.build(max_per_leaf=1, strategy=0)
+    with pytest.raises(rta.RtError, match="deeper than 64"):
+        sc.upload(gpu)
+    sc.build(max_per_leaf=2, strategy=1)
     sc.upload(gpu)
     rays = scenes.random_rays(300_000, 52, lo=(-1.7, 0, -1.7), hi=(1.7, 3.4, 1.7))
     hits = sc.trace_closest(rays)
