@@ -2,14 +2,23 @@
 """bench.py — headline benchmark of the path-tracing hot path (BASELINE.json configs[1]).
 
 Workload: cornellbox.glb (13 170 triangles) at 1920x1080, 8 bounces, GGX + Beckmann material mapping, camera from the
-file's Camera node chain, uniform 16x8 environment.  One "step" = one rt_render call tracing SPP_STEP samples per pixel
-of a (steps x SPP_STEP x n_gpus)-sample Hammersley set; the default 32 steps x 32 spp = the configuration's 1024 spp (rt_render cuts a step into four 8-spp wavefront passes in flight).
-Multi-GPU: sample-pass sharding — rank r renders its own window of sample indices (no data-path collective) and ONE
-RCCL reduce of the fp32 radiance buffer to rank 0 closes the frame (inside the timed region).
+file's Camera node chain, uniform 16x8 environment.  One "step" = SPP_STEP (32) samples per pixel over the whole frame =
+one rt_render call (cut by the library into four 8-spp wavefront passes in flight); the default 32 steps are the
+configuration's 1024 spp.
+
+Multi-GPU (one process per GPU, torch.distributed for the launch, the barriers and the statistics):
+  --scaling strong (default)  the frame is FIXED: steps x SPP_STEP samples per pixel of ONE Hammersley set.  With
+                              --sharding samples each rank renders its contiguous window of the set, with --sharding tiles
+                              its interleaved 64x64 tiles (rt_render_tiles) at all samples.  T_1 / (G T_G) is the north
+                              star's scaling efficiency; the frame is the 1-GPU frame up to fp32 summation order.
+  --scaling weak              every rank renders steps x SPP_STEP samples of a (world x that)-sample set.
+Either way the ranks share nothing while rendering (no data-path collective) and ONE reduce of the fp32 radiance buffer
+to rank 0 — rt_reduce of the C-ABI: RCCL over xGMI — closes the frame inside the timed region.
 
 Prints ONE JSON line on rank 0.  `value` = (closest-hit + shadow rays actually traced, all ranks) / wall seconds, rays
 counted by device counters, radiance accumulated in HBM (device output, nothing crosses PCIe in the timed region)."""
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -20,11 +29,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 32  # (main() raises the raster for --workload spheres10m)
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-VISITS_JSON = os.path.join(ROOT, "profiles", "visits_cornellbox_1080p_d8.json")
-# rocprofv3 --pmc passes over `bench.py --steps 1` (tools/profile_pmc.sh + tools/summarize_pmc.py), FETCH_SIZE doubled as
-# MI355X_MICROARCH.md prescribes for gfx950; roofline.traffic = HBM bytes per launch of the dominant kernel from it
-PMC_JSON = os.path.join(ROOT, "profiles", "r01_pmc_summary_final.json")
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; L2 (4 MiB per XCD, 32 MiB aggregate) ~34.5 TB/s; LDS ~150 TB/s for ds_read_b64/b128 with every CU streaming
+HBM_PEAK_GBPS, L2_PEAK_GBPS, LDS_PEAK_GBPS = 8000.0, 34500.0, 150000.0
+PROFILE_ROUND = "r02"
+
+
+def kernel_source_sha16():
+    """Identifies the kernels a counter summary was measured on: sha256 over the device sources."""
+    h = hashlib.sha256()
+    for name in ("rt_device.h", "rt_hip.hip"):
+        with open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
@@ -71,6 +87,70 @@ def cpu_baseline(scenes, rta, sc, seconds_target=15.0):
     }
 
 
+def roofline(args, stats, alone, visits, two_level):
+    """The dominant kernel against its roofs.
+
+    bound "hbm": `achieved` = HBM bytes the kernel moves per launch (rocprofv3 PMC passes over THIS kernel source,
+    FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes, + WRITE_SIZE) / its stand-alone launch duration, measured live in
+    this run (HIP events on the launching stream, one pass at a time).  null when no counter summary matches the loaded
+    kernels: an algorithmic figure is never printed as an HBM fraction.
+    The algorithmic bytes (SURVEY 8 d: 64 B per pair record visited, 52 B per triangle tested, 48 B per ray; visit counts from
+    the oracle's instrumented walk) are reported beside it, split by the level that serves them — the LDS copy of the tree
+    top, and everything behind the vector L1 — each against that level's peak."""
+    kern = "k_closest" if alone["ms_closest"] >= alone["ms_shadow"] else "k_shadow"
+    which = "closest" if kern == "k_closest" else "shadow"
+    v = visits[which]
+    a_rays, a_ms, a_n = alone[f"rays_{which}"], alone[f"ms_{which}"], max(alone[f"launches_{which}"], 1)
+    f_rays, f_ms, f_n = stats[f"rays_{which}"], stats[f"ms_{which}"], max(stats[f"launches_{which}"], 1)
+    kernel_name = kern + ("2" if two_level else "")
+    launch_s = a_ms * 1e-3 / a_n
+    alg_bytes = a_rays * v["bytes_per_ray"] / a_n
+    out = {"bound": "hbm", "kernel": kernel_name, "achieved": None, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+           "avg_launch_ms": a_ms / a_n, "launches": a_n, "rays_per_launch": a_rays / a_n,
+           "timing": "stand-alone: one untimed extra step with one pass at a time (RT_RENDER_SERIAL), HIP events around each launch",
+           "in_flight": {"avg_launch_ms": f_ms / f_n, "launches": f_n,
+                         "note": "event brackets of the timed steps: up to four passes share the GPU, a bracket includes its neighbours' work"}}
+    pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_summary_{args.workload}.json")
+    counters = {"file": os.path.relpath(pmc_path, ROOT), "matches_loaded_kernels": False}
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path))
+        meta = pmc.get("_meta", {})
+        counters["measured_on_source_sha16"] = meta.get("source_sha16")
+        counters["matches_loaded_kernels"] = meta.get("source_sha16") == kernel_source_sha16() and meta.get("max_per_leaf") == args.max_per_leaf
+        k = pmc.get(kernel_name, {})
+        if counters["matches_loaded_kernels"] and k.get("dispatches"):
+            for name in ("valu_active_lanes_of_64", "l2_hit_rate", "mean_waves_per_busy_cycle", "valu_busy_frac", "lds_bank_conflict_cycles_per_lds_inst",
+                         "SQ_WAIT_ANY_frac_of_wave_cycles"):
+                if name in k:
+                    counters[name] = k[name]
+            if "hbm_read_bytes_corrected" in k and "hbm_write_bytes" in k:
+                out["traffic"] = (k["hbm_read_bytes_corrected"] + k["hbm_write_bytes"]) / k["dispatches"]
+                out["achieved"] = out["traffic"] / launch_s / 1e9
+                out["frac"] = out["achieved"] / HBM_PEAK_GBPS
+    out["counters"] = counters
+    alg = {"bytes_per_launch": alg_bytes, "bytes_per_ray": v["bytes_per_ray"], "gbps": alg_bytes / launch_s / 1e9,
+           "inner_per_ray": v["inner_per_ray"], "triangles_per_ray": v["leaf_per_ray"]}
+    # share of the inner visits that read the LDS copy of the tree top (records [0, 256)): counted on the GPU by the -DRT_STATS
+    # build of the walks (tools/lane_stats.py)
+    lane_path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_lane_stats_{args.workload}.json")
+    top = None
+    if os.path.exists(lane_path):
+        lane = json.load(open(lane_path))
+        if lane.get("max_per_leaf") == args.max_per_leaf:
+            top = lane.get(which, {}).get("inner_from_lds_top_frac")
+            alg["lanes_per_inner_step"] = lane.get(which, {}).get("lanes_per_inner_step")
+    if top is not None:
+        lds_bytes = a_rays * 64.0 * v["inner_per_ray"] * top / a_n
+        rest = alg_bytes - lds_bytes
+        alg["served_by"] = {
+            "lds": {"gbps": lds_bytes / launch_s / 1e9, "peak": LDS_PEAK_GBPS, "frac": lds_bytes / launch_s / 1e9 / LDS_PEAK_GBPS},
+            "l1_l2_hbm": {"gbps": rest / launch_s / 1e9, "peak": L2_PEAK_GBPS, "frac": rest / launch_s / 1e9 / L2_PEAK_GBPS,
+                          "note": "everything behind the vector L1, priced against the L2 peak; what of it reaches HBM is `traffic`"},
+        }
+    out["algorithmic"] = alg
+    return out
+
+
 def main():
     global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
@@ -78,7 +158,7 @@ def main():
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--spp-per-pass", type=int, default=0)
-    ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel traced by one step (one rt_render call)")
+    ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel of one step (one rt_render call over the whole frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-per-leaf", type=int, default=None, help="max_per_node of BVH::build (1 = what the reference's TriangleMesh passes); "
                     "default: 2, random1m 1 (instanced5m: TriangleMesh(mesh, max_per_node))")
@@ -86,6 +166,12 @@ def main():
                     help="cornellbox = BASELINE configs[1] (the headline); random1m = configs[2], 1M random triangles, primary + shadow "
                          "rays only; spheres10m = configs[3] geometry on ONE GPU: 9.6M-triangle sphere field, 3840x2160, 8 bounces; "
                          "instanced5m = configs[4] as a TWO-LEVEL scene: one 100k-triangle mesh placed 50 times by Instance transforms")
+    ap.add_argument("--sharding", choices=["samples", "tiles"], default=None,
+                    help="multi-GPU partition: sample windows of the one sample set (default), or interleaved 64x64 image tiles "
+                         "(default for instanced5m*: BASELINE configs[4])")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong",
+                    help="strong: the frame (steps x spp-step samples per pixel) is fixed and split over the GPUs; weak: every GPU renders that much")
+    ap.add_argument("--tile", type=int, default=64, help="tile edge of --sharding tiles")
     args = ap.parse_args()
 
     import numpy as np
@@ -103,7 +189,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if rta.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # RT_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend — exercises the N > 1 control path (windows, barriers,
+    # RT_BENCH_REHEARSE=1: every rank on GPU 0 with the gloo backend — exercises the N > 1 control path (partitions, barriers,
     # max-over-ranks timing, the frame reduce through a host copy) on a one-GPU box; its numbers mean nothing
     rehearse = bool(os.environ.get("RT_BENCH_REHEARSE"))
     if rehearse:
@@ -118,86 +204,142 @@ def main():
 
     if args.max_per_leaf is None:  # measured per workload: random1m walks 3 % slower with two triangles per leaf, the others 5-8 % faster
         args.max_per_leaf = 1 if args.workload == "random1m" else 2
-    # ---- scene: load, build the BVH on the host, flatten, upload once
+    if args.sharding is None:
+        args.sharding = "tiles" if args.workload.startswith("instanced5m") else "samples"
+    if args.sharding == "tiles" and args.scaling == "weak":
+        raise SystemExit("--sharding tiles splits a fixed frame: use --scaling strong")
+
+    # ---- scene: load, build the BVH on the host ONCE (rank 0; the other ranks take its nodes), flatten, upload
     t0 = time.time()
     depth = DEPTH
-    visits_json = VISITS_JSON
+    two_level = False
+    visits_name = "visits_cornellbox_1080p_d8"
     if args.workload == "cornellbox":
         sc = scenes.cornellbox(rta)
-        # BVH::build(bounds, max_per_node, BVH_SAH) (BVH.h:29): the reference's own builder.  Its legacy TriangleMesh passes
-        # 1 (Object.cpp:21); Mesh::build of the target design is declared and never written (Mesh.h:24).  Two triangles per
-        # leaf walk 5 % faster with identical hits (6.75 -> 7.07 Grays/s; 3: 6.65, 4: 6.42, 8: 5.25).
-        sc.build(max_per_leaf=args.max_per_leaf)
-        cam = scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
+        cam_of = lambda: scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
         label = "cornellbox.glb"
     elif args.workload == "random1m":  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
         sc = scenes.random_triangles(rta, 1_000_000)
-        sc.build(max_per_leaf=args.max_per_leaf)  # the reference's SAH builder (multi-threaded, same output)
-        cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
+        cam_of = lambda: scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
         depth = 1
-        visits_json = os.path.join(ROOT, "profiles", "visits_random1m_1080p_d1.json")
+        visits_name = "visits_random1m_1080p_d1"
         label = "1M random triangles (seed 1234), one rectangle light"
     elif args.workload == "instanced5m":  # BASELINE configs[4], kept two-level: TLAS + ONE mesh BVH + per-instance ray transforms
         sc = scenes.legacy_instanced(rta, max_per_leaf=args.max_per_leaf)  # TriangleMesh(mesh, max_per_node); the reference's constant is 1
-        sc.build()
-        cam = scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
-        visits_json = os.path.join(ROOT, "profiles", "visits_instanced5m_1080p_d8.json")
+        cam_of = lambda: scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
+        visits_name = "visits_instanced5m_1080p_d8"
+        two_level = True
         label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), rectangle light + uniform environment"
     elif args.workload == "instanced5m_flat":  # the same surfaces flattened into one 5 M-triangle world-space mesh (Scene::add_instance)
         sc = scenes.legacy_instanced_flat(rta)
-        sc.build(max_per_leaf=args.max_per_leaf)
-        cam = scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
-        visits_json = os.path.join(ROOT, "profiles", "visits_instanced5m_flat_1080p_d8.json")
+        cam_of = lambda: scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
+        visits_name = "visits_instanced5m_flat_1080p_d8"
         label = "room + one 99 856-triangle mesh x 50, FLATTENED into one 5 M-triangle mesh, rectangle light + uniform environment"
     else:  # BASELINE configs[3] geometry, one GPU's share: 614 MB of pair records + 922 MB of triangles and normals, beyond every cache
         WIDTH, HEIGHT = 3840, 2160
         sc = scenes.sphere_field(rta)
-        sc.build(max_per_leaf=args.max_per_leaf)
-        cam = scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
         sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
-        visits_json = os.path.join(ROOT, "profiles", "visits_spheres10m_4k_d8.json")
+        cam_of = lambda: scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
+        visits_name = "visits_spheres10m_4k_d8"
         label = "10 000 tessellated spheres (9.6M triangles, seed 1234), rectangle light + uniform environment"
+    bvh_shared = False
+    if two_level:
+        sc.build()  # (the mesh BVH was built by new_triangle_mesh: 0.2 s)
+    elif world > 1:
+        # the SAH build is the expensive part of set-up (9 s at 9.6 M triangles on 16 threads): rank 0 builds, the others load its tree
+        cache = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"rt_bench_bvh_{args.workload}_{args.max_per_leaf}_{os.environ.get('MASTER_PORT', '0')}.npz")
+        if rank == 0:
+            sc.build(max_per_leaf=args.max_per_leaf)
+            np.savez(cache, nodes=sc.array(rta.ARR_NODES), indices=sc.array(rta.ARR_INDICES))
+        dist.barrier()
+        if rank != 0:
+            with np.load(cache) as z:
+                sc.set_bvh(z["nodes"], z["indices"])
+        dist.barrier()
+        if rank == 0:
+            os.remove(cache)
+        bvh_shared = True
+    else:
+        # BVH::build(bounds, max_per_node, BVH_SAH) (BVH.h:29): the reference's own builder.  Its legacy TriangleMesh passes
+        # 1 (Object.cpp:21); Mesh::build of the target design is declared and never written (Mesh.h:24).  Two triangles per
+        # leaf walk 5 % faster with identical hits (3: 6.65, 4: 6.42, 8: 5.25 Grays/s against 7.07).
+        sc.build(max_per_leaf=args.max_per_leaf)
+    cam = cam_of()
     label = f"{label}, BVH::build(bounds, {args.max_per_leaf}, BVH_SAH),"
-    if args.max_per_leaf == 2:  # visit statistics are per tree (tools/measure_visits.py <workload>_leaf2)
-        visits_json = visits_json[:-5] + "_leaf2.json"
-    elif args.max_per_leaf != 1:
-        visits_json = ""  # no visit statistics for this tree: no roofline
+    visits_json = os.path.join(ROOT, "profiles", visits_name + ("_leaf2" if args.max_per_leaf == 2 else "") + ".json")
+    if args.max_per_leaf not in (1, 2):
+        visits_json = ""  # no visit statistics for this tree: no algorithmic figures
     t_build = time.time() - t0
     sc.upload(local_rank)
 
+    # ---- this rank's share of the frame
     K, W = args.steps, args.warmup
     spp_step = args.spp_step
-    first, _, spp_total = sharding.sample_window(rank, world, K * spp_step)  # this rank's window of the Hammersley set
+    tiles = None
+    if args.scaling == "weak":
+        first, count, spp_total = sharding.sample_window(rank, world, K * spp_step)
+    elif args.sharding == "samples":
+        first, count, spp_total = sharding.strong_sample_window(rank, world, K * spp_step)
+    else:
+        first, count, spp_total = 0, K * spp_step, K * spp_step
+        tiles = rta.shard_tiles(rank, world, WIDTH, HEIGHT, args.tile) if world > 1 else None
+    calls = [(first + b, min(spp_step, count - b)) for b in range(0, count, spp_step)]  # this rank's rt_render calls of the timed region
     frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
+    scratch = torch.zeros_like(frame)
+    torch.cuda.synchronize()  # the library works on its own streams: the fills must have finished (include/rt_hip.h, RT_RENDER_DEVICE_OUT)
 
-    def step(i, timing, serial=False, target=None):
-        _, st = sc.render(cam, WIDTH, HEIGHT, spp=spp_step, max_depth=depth, seed=1, spp_begin=first + (i % K) * spp_step,
-                          spp_total=spp_total, spp_per_pass=args.spp_per_pass, device_out=(target if target is not None else frame).data_ptr(),
-                          timing=timing, serial=serial)
+    def render(begin, n, timing, serial=False, target=None):
+        _, st = sc.render(cam, WIDTH, HEIGHT, spp=n, max_depth=depth, seed=1, spp_begin=begin, spp_total=spp_total, spp_per_pass=args.spp_per_pass,
+                          device_out=(target if target is not None else frame).data_ptr(), timing=timing, serial=serial, tiles=tiles)
         return st
 
-    for i in range(W):
-        step(i, False)
-    frame.zero_()
+    # the frame's reduce: rt_reduce (RCCL through the C-ABI); the one-GPU rehearsal goes through a host copy and gloo
+    comm = None
+    reduce_path = "none (one GPU)"
+    if world > 1 and not rehearse:
+        uid = torch.from_numpy(rta.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(f"cuda:{local_rank}")
+        dist.broadcast(uid, src=0)
+        try:
+            comm = rta.Comm.create(uid.cpu().numpy(), rank, world, local_rank)
+            reduce_path = "rt_reduce (C-ABI, RCCL ncclReduce over xGMI)"
+        except rta.RtError as e:  # loud, and the run still measures: the same collective through torch's RCCL
+            print(f"bench.py: rank {rank}: rt_comm_create failed ({e}); the frame reduce falls back to torch.distributed", file=sys.stderr, flush=True)
+            reduce_path = "torch.distributed.reduce (RCCL) — rt_comm_create failed, see stderr"
+        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:  # all ranks must take the same path
+            comm.close()
+            comm = None
+            reduce_path = "torch.distributed.reduce (RCCL) — rt_comm_create failed on another rank"
+    elif world > 1:
+        reduce_path = "gloo through a host copy (RT_BENCH_REHEARSE)"
+
+    def reduce_frame(buf):
+        if world == 1:
+            return
+        if comm is not None:
+            comm.reduce(buf.data_ptr(), buf.numel(), 0)
+        elif rehearse:
+            host = buf.cpu()
+            sharding.reduce_frame(host, dst=0)
+            buf.copy_(host)
+        else:
+            sharding.reduce_frame(buf, dst=0)
+
+    for i in range(W):  # warm-up: W full-size calls + the collective's first use (channel set-up is not the frame's cost)
+        render(first, min(spp_step, count), False, target=scratch)
+    if W > 0 or world > 1:
+        reduce_frame(scratch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     stats = None
-    for i in range(K):
-        st = step(i, True)
-        if stats is None:
-            stats = dict(st)
-        else:
-            for k in st:
-                stats[k] += st[k]
-    if rehearse and world > 1:
-        host = frame.cpu()
-        sharding.reduce_frame(host, dst=0)
-        frame.copy_(host)
-    else:
-        sharding.reduce_frame(frame, dst=0)  # the frame's single RCCL reduce over xGMI (no-op at world 1)
+    for begin, n in calls:
+        st = render(begin, n, True)
+        stats = dict(st) if stats is None else {k: stats[k] + st[k] for k in st}
+    reduce_frame(frame)  # the frame's single reduce (no-op at world 1)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -215,6 +357,9 @@ def main():
 
     if rank == 0:
         rays = rays_c + rays_s
+        total_spp = K * spp_step * (world if args.scaling == "weak" else 1)
+        share = (f"sample-pass sharding: {count} spp per GPU" if args.sharding == "samples" else f"image-tile sharding: interleaved {args.tile}x{args.tile} tiles, "
+                 f"{len(tiles) if tiles is not None else 'all'} per GPU") if world > 1 else "one GPU"
         out = {
             "metric": "Mrays/s and samples/s per GPU (1/2/4/8 MI355X), 1080p cornellbox, 8 bounces",
             "value": rays / elapsed / 1e6,
@@ -225,63 +370,40 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed * 1000.0 / K,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{label} {WIDTH}x{HEIGHT}, {depth} bounces, " + ("GGX+Beckmann materials, " if args.workload == "cornellbox" else "") + f"{spp_step} spp per step, "
-                            f"{K * spp_step} spp per GPU ({spp_total}-sample Hammersley set), sample-pass sharding + one reduce",
+                "workload": f"{label} {WIDTH}x{HEIGHT}, {depth} bounces, " + ("GGX+Beckmann materials, " if args.workload == "cornellbox" else "") +
+                            f"{spp_step} spp per step, frame of {total_spp} spp ({spp_total}-sample Hammersley set), {share} + one reduce",
                 "triangles": int(len(sc.array(rta.ARR_TRIS))) if args.workload != "instanced5m" else int(len(sc.array(rta.ARR_FLAT_TRIS))),
                 "instances": int(len(sc.array(rta.ARR_INSTANCES))),
+                "sharding": args.sharding if world > 1 else None,
+                "reduce": reduce_path,
+                "bvh_built_once_and_shared": bvh_shared,
                 "rays_closest": rays_c,
                 "rays_shadow": rays_s,
                 "rays_per_sample": rays / paths,
                 "bvh_build_s": t_build,
-                "frame_mean": float(frame.mean().item()) / (K * spp_step * world),
+                "frame_mean": float(frame.mean().item()) / total_spp,
             },
         }
-        # ---- roofline of the dominant kernel (rank 0's own launches, HIP events on the library's stream)
-        visits = json.load(open(visits_json)) if os.path.exists(visits_json) else None
-        kern = "k_closest" if stats["ms_closest"] >= stats["ms_shadow"] else "k_shadow"  # (k_closest2 / k_shadow2 on a two-level scene)
-        if visits and max(stats["ms_closest"], stats["ms_shadow"]) > 0:
-            v = visits["closest" if kern == "k_closest" else "shadow"]
-            n_rays = stats["rays_closest"] if kern == "k_closest" else stats["rays_shadow"]
-            ms = stats["ms_closest"] if kern == "k_closest" else stats["ms_shadow"]
-            launches = stats["launches_closest"] if kern == "k_closest" else stats["launches_shadow"]
-            gbps = n_rays * v["bytes_per_ray"] / (ms * 1e-3) / 1e9
-            traffic = None
-            # HBM bytes per launch from the PMC passes of tools/profile_pmc.sh over this workload and tree (two-level kernels
-            # are listed as k_closest2 / k_shadow2)
-            pmc_json = PMC_JSON if args.workload == "cornellbox" else os.path.join(ROOT, "profiles", f"r01_pmc_summary_{args.workload}.json")
-            if os.path.exists(pmc_json) and args.max_per_leaf == (1 if args.workload == "random1m" else 2):
-                pmc = json.load(open(pmc_json))
-                pmc = pmc.get(kern + "2", {}) if args.workload == "instanced5m" else pmc.get(kern, {})
-                if pmc.get("dispatches") and "hbm_read_bytes_corrected" in pmc and "hbm_write_bytes" in pmc:
-                    traffic = (pmc["hbm_read_bytes_corrected"] + pmc["hbm_write_bytes"]) / pmc["dispatches"]
-            out["roofline"] = {
-                "bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-                "traffic": traffic, "algorithmic_bytes_per_launch": n_rays * v["bytes_per_ray"] / max(launches, 1), "kernel": kern, "bytes_per_ray": v["bytes_per_ray"], "rays_per_launch": n_rays / max(launches, 1),
-                "avg_launch_ms": ms / max(launches, 1), "launches": launches,
-            }
-            # the same kernel alone on the GPU: one untimed step with one sample pass at a time (RT_RENDER_SERIAL).  In the
-            # timed region up to four passes share the GPU, so a launch's event-bracketed duration includes its neighbours' work.
-            scratch = torch.zeros_like(frame)
-            step(0, True, serial=True, target=scratch)
-            alone = step(1 % K, True, serial=True, target=scratch)
-            a_rays = alone["rays_closest"] if kern == "k_closest" else alone["rays_shadow"]
-            a_ms = alone["ms_closest"] if kern == "k_closest" else alone["ms_shadow"]
-            a_n = alone["launches_closest"] if kern == "k_closest" else alone["launches_shadow"]
-            a_gbps = a_rays * v["bytes_per_ray"] / (a_ms * 1e-3) / 1e9
-            out["roofline"]["standalone"] = {"achieved": a_gbps, "frac": a_gbps / HBM_PEAK_GBPS, "avg_launch_ms": a_ms / max(a_n, 1),
-                                             "launches": a_n, "ms_per_step": alone["ms_total"],
-                                             "note": "untimed extra step, one pass at a time" + ("; the tree is L2/LDS-resident on cornellbox, so "
-                                                     "algorithmic bytes are not HBM bytes (see traffic)" if args.workload == "cornellbox" else "")}
+        # ---- roofline of the dominant kernel: one untimed extra step with one pass at a time, so that a launch's duration is its own
+        visits = json.load(open(visits_json)) if visits_json and os.path.exists(visits_json) else None
+        if visits:
+            render(first, min(spp_step, count), True, serial=True, target=scratch)
+            alone = render(first, min(spp_step, count), True, serial=True, target=scratch)
+            out["roofline"] = roofline(args, stats, alone, visits, two_level)
+            out["kernel_ms_standalone_step"] = {k: alone[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
         out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
         if not args.no_cpu_baseline and world == 1 and args.workload == "cornellbox":
             out["cpu_baseline"] = cpu_baseline(scenes, rta, sc)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

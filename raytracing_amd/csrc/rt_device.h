@@ -770,17 +770,26 @@ RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& 
 template <bool ANY, class Sink>
 RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
                          const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
-                         lds_int* lds, lds_cf4* top, int top_bytes, Sink sink) {
+                         lds_int* lds, lds_int* hrec, lds_cf4* top, int top_bytes, Sink sink) {
     int spill[RT_TL_STACK_TOTAL - RT_SHORT_STACK];
     V3 o(0.f), d(0.f); // the lane's current ray
     RaySlab rs;
     rs.oxy = rs.ozz = rs.ixy = rs.izz = f2{0.f, 0.f};
-    Hit2 h;
-    h.slot = h.inst = -1;
-    h.t = INFINITY;
-    h.u = h.v = 0.f;
-    h.n = V3(0.f);
-    h.front = true;
+    // The closest hit's record beyond its distance (u, v, slot, instance | front, normal) is written when a hit is accepted
+    // and read once, when the ray completes: it lives in LDS (hrec: seven words per lane, column layout like the stack),
+    // not in seven registers of a walk that is compiled for 64 (the register version spilled 31 of them to scratch).
+    // Occlusion queries (ANY) keep no record at all.
+    auto hit_store = [&](float u, float v, int slot, int inst_front, const V3& n) {
+        if (ANY) return;
+        hrec[0 * RT_TRAV_BLOCK] = __float_as_int(u);
+        hrec[1 * RT_TRAV_BLOCK] = __float_as_int(v);
+        hrec[2 * RT_TRAV_BLOCK] = slot;
+        hrec[3 * RT_TRAV_BLOCK] = inst_front;
+        hrec[4 * RT_TRAV_BLOCK] = __float_as_int(n.x);
+        hrec[5 * RT_TRAV_BLOCK] = __float_as_int(n.y);
+        hrec[6 * RT_TRAV_BLOCK] = __float_as_int(n.z);
+    };
+    bool found = false;
     float t_best = INFINITY, t_local = INFINITY, tcull = INFINITY;
     uint32_t q = 0;
     bool exact = false, wave_exact = false;
@@ -812,11 +821,7 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
                 t_best = tmax_in; // closest_so_far (Scene.h:117) / Scene::closest_hit's t (Scene.cpp:25)
                 t_local = INFINITY;
                 tcull = (tmax_in > 0.f && tmax_in < INFINITY) ? tmax_in * 1.0001f + 0.000001f : (tmax_in <= 0.f ? tmax_in : INFINITY);
-                h.slot = h.inst = -1;
-                h.t = INFINITY;
-                h.u = h.v = 0.f;
-                h.n = V3(0.f);
-                h.front = true;
+                found = false;
                 sp = 0;
                 in_inst = -1;
                 cur = sc.n_inst > 0 ? sc.tl_root : RT_CUR_FINISH;
@@ -869,11 +874,8 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
                     if (tri_accept(o, d, a, b, c, t_best, &tt, &u, &v)) {
                         t_best = tt;
                         t_local = tt;
-                        h.t = tt;
-                        h.u = u;
-                        h.v = v;
-                        h.slot = slot;
-                        h.inst = in_inst;
+                        found = true;
+                        hit_store(u, v, slot, in_inst | 0x40000000, V3(0.f));
                         if (ANY) stop = last = true;
                     }
                     slot++;
@@ -903,20 +905,31 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
                     bool stop = false;
                     if (prim_intersect(geometry, p, mo, md, 0.f, t_best, &g)) {
                         t_best = g.t;
-                        h.t = g.t;
-                        h.u = g.u;
-                        h.v = g.v;
-                        h.n = g.n;
-                        h.front = g.front;
-                        h.slot = -2;
-                        h.inst = k;
+                        found = true;
+                        hit_store(g.u, g.v, -2, k | (g.front ? 0x40000000 : 0), g.n);
                         stop = ANY;
                     }
                     cur = stop ? RT_CUR_HIT : pop();
                 }
             }
             if (cur == RT_CUR_FINISH || cur == RT_CUR_HIT) {
-                sink(q, h, ANY ? cur == RT_CUR_HIT : h.inst >= 0);
+                Hit2 h;
+                h.slot = h.inst = -1;
+                h.t = INFINITY;
+                h.u = h.v = 0.f;
+                h.n = V3(0.f);
+                h.front = true;
+                if (!ANY && found) {
+                    h.t = t_best;
+                    h.u = __int_as_float(hrec[0 * RT_TRAV_BLOCK]);
+                    h.v = __int_as_float(hrec[1 * RT_TRAV_BLOCK]);
+                    h.slot = hrec[2 * RT_TRAV_BLOCK];
+                    const int inst_front = hrec[3 * RT_TRAV_BLOCK];
+                    h.inst = inst_front & 0x3fffffff;
+                    h.front = (inst_front & 0x40000000) != 0;
+                    h.n = V3(__int_as_float(hrec[4 * RT_TRAV_BLOCK]), __int_as_float(hrec[5 * RT_TRAV_BLOCK]), __int_as_float(hrec[6 * RT_TRAV_BLOCK]));
+                }
+                sink(q, h, ANY ? cur == RT_CUR_HIT : found);
                 cur = RT_CUR_DONE;
                 exact = false;
             }

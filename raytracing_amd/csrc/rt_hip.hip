@@ -211,7 +211,8 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK, RT_TL_WAVES) void k_closest2(SceneVi
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
     const int top_bytes = stage_tree_top(sc, s_top);
-    trace_queue2<false>(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+    __shared__ int hit_rec[7 * RT_TRAV_BLOCK]; // the closest hit's record beyond its distance (trace_queue2)
+    trace_queue2<false>(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_int*)hit_rec + threadIdx.x, (lds_cf4*)s_top, top_bytes,
                         [&](uint32_t q, const Hit2& h, bool) {
                             int slot = h.slot;
                             if (want_tri_id && slot != -1) slot = slot >= 0 ? (int)(__float_as_uint(sc.tris[3 * (size_t)slot].w) & ~RT_TRI_LEAF_END) : 0;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK, RT_TL_WAVES) void k_shadow2(SceneVie
     __shared__ int stack[RT_SHORT_STACK * RT_TRAV_BLOCK];
     __shared__ float4 s_top[RT_TOP_LDS_BYTES / 16];
     const int top_bytes = stage_tree_top(sc, s_top);
-    trace_queue2<true>(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+    trace_queue2<true>(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, nullptr, (lds_cf4*)s_top, top_bytes,
                        [&](uint32_t q, const Hit2&, bool occluded) { out[q] = (uint8_t)(occluded ? on_hit : 1 - on_hit); });
 }
 

@@ -41,12 +41,20 @@ dist.destroy_process_group()
 """
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _launch(mode, tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(f"ROOT = {ROOT!r}\n" + WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", str(script), mode]
+           "--master-port", str(_free_port()), str(script), mode]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert f"OK {mode}" in out.stdout

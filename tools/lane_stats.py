@@ -13,9 +13,13 @@ import scenes
 
 lib = C.CDLL(os.path.join(ROOT, "raytracing_amd", "librt_hip.so"), mode=C.RTLD_GLOBAL)
 buf = (C.c_ulonglong * 16)()
+import json
+
+PER_LEAF = int(sys.argv[1]) if len(sys.argv) > 1 else 2  # the tree bench.py walks: BVH::build(bounds, 2, BVH_SAH)
 sc = scenes.cornellbox(rta)
-sc.build()
+sc.build(max_per_leaf=PER_LEAF)
 sc.upload(0)
+summary = {"workload": "cornellbox", "max_per_leaf": PER_LEAF, "sample": "1920x1080, 4 spp (samples 4..7 of 1024), depth 8, -DRT_STATS build of the walks"}
 cam = scenes.cornell_camera(rta, sc, 1920, 1080)
 sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=0, spp_total=1024)
 lib.rt_debug_lane_stats(buf)  # warm-up discarded
@@ -28,6 +32,12 @@ for name, base, rays in (("closest", 0, st["rays_closest"]), ("occlusion", 8, st
     print(f"  inner steps: {inner_w} wave-steps, {inner_l / max(inner_w, 1):.1f} lanes each, {inner_l / rays:.2f} per ray")
     print(f"  inner steps read from the LDS tree top: {100.0 * top_l / max(inner_l, 1):.1f} %")
     print(f"  leaf turns : {leaf_w} wave-turns, {leaf_l / max(leaf_w, 1):.1f} lanes each, {leaf_l / rays:.2f} per ray")
+    summary["closest" if base == 0 else "shadow"] = {
+        "rays": int(rays), "inner_steps_per_ray": inner_l / rays, "lanes_per_inner_step": inner_l / max(inner_w, 1),
+        "inner_from_lds_top_frac": top_l / max(inner_l, 1), "leaf_turns_per_ray": leaf_l / rays, "lanes_per_leaf_turn": leaf_l / max(leaf_w, 1),
+        "lanes_holding_a_ray_per_round": held / max(rounds, 1)}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "lane_stats_cornellbox.json"), "w"), indent=1)
 
 sbuf = (C.c_ulonglong * 32)()
 if hasattr(lib, "rt_debug_shade_stats"):

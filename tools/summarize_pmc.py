@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
 """Sums rocprofv3 --pmc counter_collection CSVs per kernel and prints derived figures.
-usage: tools/summarize_pmc.py <dir with one sub-directory per pass> [out.json]"""
+usage: tools/summarize_pmc.py <dir with one sub-directory per pass> [out.json] [workload] [max_per_leaf]
+The summary carries `_meta.source_sha16` (sha256 over the device sources it was measured on): bench.py prints counter-derived
+figures only when that matches the kernels it runs."""
 import csv
 import glob
 import json
 import os
+import hashlib
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 root = sys.argv[1]
 tot = defaultdict(lambda: defaultdict(float))
@@ -38,12 +43,25 @@ for k, c in sorted(tot.items()):
                 d[n + "_frac_of_wave_cycles"] = c[n] / c["SQ_WAVE_CYCLES"]
     if c.get("TCC_HIT_sum") is not None and (c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0)) > 0:
         d["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if c.get("SQ_INSTS_VALU") and c.get("GRBM_GUI_ACTIVE"):
+        # a wave64 vector instruction occupies its SIMD for 4 cycles; GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles, each XCD has
+        # 32 CUs x 4 SIMDs: the share of SIMD cycles spent issuing vector arithmetic
+        d["valu_busy_frac"] = 4.0 * c["SQ_INSTS_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    if c.get("SQ_INSTS_LDS") and "SQ_LDS_BANK_CONFLICT" in c:
+        d["lds_bank_conflict_cycles_per_lds_inst"] = c["SQ_LDS_BANK_CONFLICT"] / c["SQ_INSTS_LDS"]
     if "FETCH_SIZE" in c:
         # MI355X_MICROARCH.md §HBM: FETCH_SIZE (KiB) reads 1/2 of a wide coalesced stream's bytes on gfx950 -> doubled
         d["hbm_read_bytes_corrected"] = 2 * c["FETCH_SIZE"] * 1024
     if "WRITE_SIZE" in c:
         d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
     out[k] = d
+h = hashlib.sha256()
+for name in ("rt_device.h", "rt_hip.hip"):
+    h.update(open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb").read())
+out["_meta"] = {"source_sha16": h.hexdigest()[:16], "workload": sys.argv[3] if len(sys.argv) > 3 else "cornellbox",
+                "max_per_leaf": int(sys.argv[4]) if len(sys.argv) > 4 else 2,
+                "collected": "rocprofv3 --kernel-trace --pmc, one run per pass (tools/profile_pmc.sh), bench.py --steps 1 --warmup 0 with "
+                             "RT_TUNE_ONE_STREAM=1: the one-stream launch geometry, kernels one after the other"}
 print(json.dumps(out, indent=1))
 if len(sys.argv) > 2:
     json.dump(out, open(sys.argv[2], "w"), indent=1)
