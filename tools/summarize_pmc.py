@@ -17,8 +17,12 @@ root = sys.argv[1]
 tot = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(lambda: defaultdict(set))
 dur = defaultdict(float)
-for path in glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv")):
+seen_in = {}  # counter -> the pass it is taken from (a counter listed in two passes, e.g. GRBM_GUI_ACTIVE, is not added up twice)
+for path in sorted(glob.glob(os.path.join(root, "*", "*", "*_counter_collection.csv"))):
+    pass_name = os.path.relpath(path, root).split(os.sep)[0]
     for row in csv.DictReader(open(path)):
+        if seen_in.setdefault(row["Counter_Name"], pass_name) != pass_name:
+            continue
         k = row["Kernel_Name"].split("(")[0].replace("void ", "")
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
         calls[k][row["Counter_Name"]].add(row["Dispatch_Id"])
