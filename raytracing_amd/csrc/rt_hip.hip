@@ -749,6 +749,15 @@ static int ensure_wave(rt_scene* s, int64_t cap, int K, int sets) {
     if (s->wave_cap >= cap && s->wave_K >= K && s->wave_sets >= sets) return RT_OK;
     free_wave(s);
     const size_t c = (size_t)cap, kc = (size_t)cap * (size_t)(K > 0 ? K : 1);
+    {   // a caller who raises spp_per_pass (or renders a huge tile) gets an error code, not an allocation failure half-way:
+        // per queue entry 8 + 1 (+1 two-level) + 1 float4 streams and 13 permutation words, per shadow slot 4 float4 + 1 byte
+        const size_t per_set = c * (16 * (8 + 1 + (s->view.inst_q ? 1 : 0) + 1) + 4 * RT_N_KEYS) + kc * (4 * 16 + 1) + (size_t)4 * RT_COUNTS * (3 * RT_CSTRIDE + 1);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && per_set * (size_t)sets > free_b)
+            return fail(RT_ERR_LIMIT, "rt_render: the wavefront buffers of this call need " + std::to_string(per_set * (size_t)sets >> 20) + " MiB (" +
+                                          std::to_string(sets) + " passes in flight x " + std::to_string(cap) + " queue entries), " +
+                                          std::to_string(free_b >> 20) + " MiB are free: lower spp_per_pass or render the frame in tiles");
+    }
     int rc;
     for (int set = 0; set < sets; set++) {
     Wave& w = s->wave[set];

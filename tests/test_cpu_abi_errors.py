@@ -215,3 +215,18 @@ def test_render_argument_checks(rta, gpu):
             sc.render(cam, 32, 32, **args)
     img, st = sc.render(cam, 32, 32, spp=4, max_depth=4)  # the handle is still usable after the refusals
     assert st["paths"] == 32 * 32 * 4 and np.isfinite(img).all()
+
+
+@pytest.mark.gpu
+def test_render_refuses_what_does_not_fit_the_gpu(rta, gpu):
+    """A pass that would need more device memory than is free is an RT_ERR_LIMIT with the sizes in the message (2^30 paths
+    per pass at ~400 B each), not a failed allocation half-way; the handle keeps working."""
+    sc = scenes.quad_room(rta)
+    sc.build()
+    sc.upload(gpu)
+    cam = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, 8192, 8192)
+    with pytest.raises(rta.RtError, match="rt error 4.*MiB"):
+        sc.render(cam, 8192, 8192, spp=16, max_depth=2, spp_per_pass=15, device_out=1 << 20)
+    small = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, 32, 32)
+    img, st = sc.render(small, 32, 32, spp=2, max_depth=2)
+    assert st["paths"] == 2048
