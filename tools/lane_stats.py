@@ -19,11 +19,12 @@ PER_LEAF = int(sys.argv[1]) if len(sys.argv) > 1 else 2  # the tree bench.py wal
 sc = scenes.cornellbox(rta)
 sc.build(max_per_leaf=PER_LEAF)
 sc.upload(0)
-summary = {"workload": "cornellbox", "max_per_leaf": PER_LEAF, "sample": "1920x1080, 4 spp (samples 4..7 of 1024), depth 8, -DRT_STATS build of the walks"}
+summary = {"workload": "cornellbox", "max_per_leaf": PER_LEAF, "sample": f"1920x1080, {os.environ.get('LS_SPP', '4')} spp per call, depth 8, -DRT_STATS build of the walks"}
 cam = scenes.cornell_camera(rta, sc, 1920, 1080)
-sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=0, spp_total=1024)
+SPP = int(os.environ.get("LS_SPP", "4"))
+sc.render(cam, 1920, 1080, spp=SPP, max_depth=8, seed=1, spp_begin=0, spp_total=1024)
 lib.rt_debug_lane_stats(buf)  # warm-up discarded
-_, st = sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=4, spp_total=1024)
+_, st = sc.render(cam, 1920, 1080, spp=SPP, max_depth=8, seed=1, spp_begin=SPP, spp_total=1024)
 assert lib.rt_debug_lane_stats(buf) == 0
 v = list(buf)
 for name, base, rays in (("closest", 0, st["rays_closest"]), ("occlusion", 8, st["rays_shadow"])):
@@ -42,7 +43,7 @@ json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "lane_stats_cornellbox.
 sbuf = (C.c_ulonglong * 32)()
 if hasattr(lib, "rt_debug_shade_stats"):
     lib.rt_debug_shade_stats(sbuf)
-    sc.render(cam, 1920, 1080, spp=4, max_depth=8, seed=1, spp_begin=8, spp_total=1024)
+    sc.render(cam, 1920, 1080, spp=SPP, max_depth=8, seed=1, spp_begin=2 * SPP, spp_total=1024)
     lib.rt_debug_shade_stats(sbuf)
     names = ["loads", "miss/env lookup", "surface+emission", "Sample_Eval", "env NEE", "light NEE", "state+next ray", "(miss lanes waiting)"]
     tot = sum(sbuf[2 * i] for i in range(7))
