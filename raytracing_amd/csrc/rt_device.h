@@ -205,6 +205,9 @@ RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_by
         const unsigned long long rr = *(const __attribute__((address_space(3))) unsigned long long*)(base + ((uint32_t)cur >> 3) + 3 * RT_TOP_Q_BYTES);
         lref = (int)(uint32_t)rr;
         rref = (int)(uint32_t)(rr >> 32);
+#ifdef RT_PROBE_LDS
+        { const int x_ = *(const __attribute__((address_space(3))) int*)(base + (at ^ 16u)); asm volatile("" ::"v"(x_)); }
+#endif
     } else {
         const f4* p = (const f4*)((const char*)pairs + (uint32_t)cur);
         q0 = p[0];
@@ -213,9 +216,24 @@ RT_DEV void load_pair(const float4* __restrict__ pairs, lds_cf4* top, int top_by
         const unsigned long long rr = *(const unsigned long long*)(p + 3); // 56 of the record's 64 bytes are read
         lref = (int)(uint32_t)rr;
         rref = (int)(uint32_t)(rr >> 32);
+#ifdef RT_PROBE_VMEM
+        { const int x_ = *((const int*)p - 2); /* the record before: records beyond the top have cur > 0 */ asm volatile("" ::"v"(x_)); }
+#endif
     }
 }
 
+// Timing probes (never in the shipped library; tools/ab.sh): N extra vector-ALU or scalar-ALU instructions per inner step (dependent
+// chains), a sleep of N x 64 cycles per inner step (latency without instruction issue), one extra LDS read per record taken from
+// the tree top, one extra load per record taken from global memory — to see what a walk is sensitive to.
+#if defined(RT_PROBE_VALU)
+#define RT_PROBE_STEP(x) do { float x_ = (x); _Pragma("unroll") for (int k_ = 0; k_ < RT_PROBE_VALU; k_++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(x_)); asm volatile("" ::"v"(x_)); } while (0)
+#elif defined(RT_PROBE_SALU)
+#define RT_PROBE_STEP(x) do { int s_ = 0; _Pragma("unroll") for (int k_ = 0; k_ < RT_PROBE_SALU; k_++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s_) : : "scc"); asm volatile("" ::"s"(s_)); } while (0)
+#elif defined(RT_PROBE_SLEEP)
+#define RT_PROBE_STEP(x) __builtin_amdgcn_s_sleep(RT_PROBE_SLEEP)
+#else
+#define RT_PROBE_STEP(x)
+#endif
 #ifndef RT_CLOSEST_STEPS
 #define RT_CLOSEST_STEPS 2 // inner steps per round of the closest walk
 #endif
@@ -271,10 +289,23 @@ __device__ unsigned long long g_rt_stats[16];
 #define RT_STAT_DECL unsigned st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define RT_STAT(i, pred) do { const unsigned long long m_ = __ballot(pred); if (m_) { st_[2 * (i)] += 1; st_[2 * (i) + 1] += (unsigned)__popcll(m_); } } while (0)
 #define RT_STAT_FLUSH(base) do { if (__lane_id() == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_rt_stats[(base) + k_], (unsigned long long)st_[k_]); } while (0)
+// ... and where a wave's cycles go (s_memtime deltas summed per wave; [0..7] closest walk, [8..15] occlusion): [0] refill,
+// [1] from a visit's start until its record has arrived (a wait is forced there), [2] the rest of the visit incl. its pop,
+// [3] leaf turns, [4] the round's own tests, [5] the cost of one mark (two marks back to back, once per round): every other
+// section contains one.
+__device__ unsigned long long g_rt_time[16];
+#define RT_TDECL unsigned long long tm_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long tprev_ = __builtin_readcyclecounter();
+#define RT_TMARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm_[i] += now_ - tprev_; tprev_ = now_; } while (0)
+#define RT_TWAIT asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#define RT_TFLUSH(base) do { if (__lane_id() == 0) for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_rt_time[(base) + k_], tm_[k_]); } while (0)
 #else
 #define RT_STAT_DECL
 #define RT_STAT(i, pred)
 #define RT_STAT_FLUSH(base)
+#define RT_TDECL
+#define RT_TMARK(i)
+#define RT_TWAIT
+#define RT_TFLUSH(base)
 #endif
 
 // Ray hand-out of the persistent traversal waves.  A queue is n_shards dense sub-queues (shard s = entries
@@ -375,6 +406,7 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
     const float4* __restrict__ pairs = sc.pairs;
     const float4* __restrict__ tris = sc.tris;
     RT_STAT_DECL
+    RT_TDECL
     QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
         if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
@@ -394,6 +426,8 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
             }
             wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
         }
+        RT_TMARK(0);
+        RT_TMARK(5);
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break; // nothing fetched: the queue is exhausted
         RT_STAT(3, cur != RT_CUR_DONE); // rounds, lanes holding a ray
 
@@ -407,10 +441,13 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 f4 q0, q1, q2;
                 int lref, rref;
                 load_pair(pairs, top, top_bytes, cur, q0, q1, q2, lref, rref);
+                RT_TWAIT;
+                RT_TMARK(1);
                 float ld, rd;
                 bool lh, rh;
                 if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
                 else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
+                RT_PROBE_STEP(ld);
                 lh = lh && ld < r.t;
                 rh = rh && rd < r.t;
                 const bool left_first = ld < rd; // ties visit the right child first (Object.h:329-336)
@@ -430,13 +467,19 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                         else cur = spill[sp - RT_SHORT_STACK];
                     }
                 }
+                RT_TWAIT;
+                RT_TMARK(2);
             }
         }
 
         // ---- leaves (Object.h:292-320) and completion: lanes that reached a leaf wait until enough of them have,
         // so the triangle test runs at a useful lane occupancy (wave-uniform decision)
         const unsigned long long at_leaf = __ballot(cur < 0 && cur != RT_CUR_DONE);
-        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) continue;
+        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) {
+            RT_TMARK(4);
+            continue;
+        }
+        RT_TMARK(4);
         if (cur < 0 && cur != RT_CUR_DONE) {
             if (cur != RT_CUR_FINISH) {
                 int slot = ~cur;
@@ -470,8 +513,11 @@ RT_DEV void trace_queue(const SceneView& sc, const float4* __restrict__ q_o, con
                 exact = false;
             }
         }
+        RT_TWAIT;
+        RT_TMARK(3);
     }
     RT_STAT_FLUSH(0);
+    RT_TFLUSH(0);
 }
 
 #define RT_CUR_HIT ((int)0x80000002)    // occlusion_queue: an occluder was found
@@ -513,6 +559,7 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
     const float4* __restrict__ pairs = sc.pairs;
     const float4* __restrict__ tris = sc.tris;
     RT_STAT_DECL
+    RT_TDECL
     QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
         if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
@@ -531,6 +578,8 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
             }
             wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
         }
+        RT_TMARK(0);
+        RT_TMARK(5);
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break;
         RT_STAT(3, cur != RT_CUR_DONE);
 #pragma unroll
@@ -541,10 +590,13 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 f4 q0, q1, q2;
                 int lref, rref;
                 load_pair(pairs, top, top_bytes, cur, q0, q1, q2, lref, rref);
+                RT_TWAIT;
+                RT_TMARK(1);
                 float ld, rd;
                 bool lh, rh;
                 if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
                 else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
+                RT_PROBE_STEP(ld);
                 lh = lh && ld < tcull;
                 rh = rh && rd < tcull;
                 const bool left_first = ld < rd;
@@ -563,10 +615,16 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                         else cur = spill[sp - RT_SHORT_STACK];
                     }
                 }
+                RT_TWAIT;
+                RT_TMARK(2);
             }
         }
         const unsigned long long at_leaf = __ballot(cur < 0 && cur != RT_CUR_DONE);
-        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) continue;
+        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) {
+            RT_TMARK(4);
+            continue;
+        }
+        RT_TMARK(4);
         if (cur < 0 && cur != RT_CUR_DONE) {
             if (cur != RT_CUR_FINISH) {
                 int slot = ~cur;
@@ -596,8 +654,11 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                 exact = false;
             }
         }
+        RT_TWAIT;
+        RT_TMARK(3);
     }
     RT_STAT_FLUSH(8);
+    RT_TFLUSH(8);
 }
 
 // ------------------------------------------------------ two-level scenes
@@ -840,6 +901,7 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
                 bool lh, rh;
                 if (!wave_exact) slab_pair<false>(q0, q1, q2, rs, ld, lh, rd, rh);
                 else slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
+                RT_PROBE_STEP(ld);
                 // inside a mesh the reference culls by the mesh's own closest hit only (t_local).  Boxes entered beyond
                 // the closest hit over ALL instances hold no triangle that can be accepted (t <= t_best, Object.h:312):
                 // they are skipped too, with occlusion_queue's margin against the rounding of the box test — same hits.

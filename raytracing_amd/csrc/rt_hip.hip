@@ -1559,6 +1559,13 @@ int rt_debug_lane_stats(unsigned long long* out16) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_rt_stats), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
     return RT_OK;
 }
+// where the walks' wave cycles went ([0..7] closest, [8..15] occlusion; sections: rt_device.h, g_rt_time)
+int rt_debug_walk_times(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rt_time), 16 * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rt_time), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
 // k_shade sections: out32[2*i] = summed wave cycles of section i, out32[2*i+1] = summed lanes that reached its end
 int rt_debug_shade_stats(unsigned long long* out32) {
     static unsigned long long host[256 * 32];

@@ -3,6 +3,7 @@
 #include "Scene.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <set>
@@ -413,7 +414,8 @@ void Scene::flatten_two_level() {
     for (Instance& inst : instances) material_index(inst.material);
     for (Instance& l : lights) material_index(l.material);
     std::map<const Geometry*, int32_t> blas_root;
-    constexpr int kTopPairs = 256;
+    // (RT_TUNE_HOST_TOP: the count for experiments with a device library built for another RT_TOP_PAIRS)
+    const int kTopPairs = std::getenv("RT_TUNE_HOST_TOP") ? std::max(1, std::atoi(std::getenv("RT_TUNE_HOST_TOP"))) : 256;
     for (const Instance& inst : instances) {
         const TriangleMesh* tm = dynamic_cast<const TriangleMesh*>(inst.get_geometry());
         if (!tm || blas_root.count(tm)) continue;

@@ -24,6 +24,9 @@ cam = scenes.cornell_camera(rta, sc, 1920, 1080)
 SPP = int(os.environ.get("LS_SPP", "4"))
 sc.render(cam, 1920, 1080, spp=SPP, max_depth=8, seed=1, spp_begin=0, spp_total=1024)
 lib.rt_debug_lane_stats(buf)  # warm-up discarded
+tbuf = (C.c_ulonglong * 16)()
+if hasattr(lib, "rt_debug_walk_times"):
+    lib.rt_debug_walk_times(tbuf)
 _, st = sc.render(cam, 1920, 1080, spp=SPP, max_depth=8, seed=1, spp_begin=SPP, spp_total=1024)
 assert lib.rt_debug_lane_stats(buf) == 0
 v = list(buf)
@@ -37,6 +40,21 @@ for name, base, rays in (("closest", 0, st["rays_closest"]), ("occlusion", 8, st
         "rays": int(rays), "inner_steps_per_ray": inner_l / rays, "lanes_per_inner_step": inner_l / max(inner_w, 1),
         "inner_from_lds_top_frac": top_l / max(inner_l, 1), "leaf_turns_per_ray": leaf_l / rays, "lanes_per_leaf_turn": leaf_l / max(leaf_w, 1),
         "lanes_holding_a_ray_per_round": held / max(rounds, 1)}
+if hasattr(lib, "rt_debug_walk_times"):
+    lib.rt_debug_walk_times(tbuf)
+    t = list(tbuf)
+    parts = ["refill", "record wait", "visit arithmetic + pop", "leaf turns", "round tests"]
+    for name, base in (("closest", 0), ("occlusion", 8)):
+        rounds = v[base + 6] or 1
+        mark = t[base + 5] / rounds  # cycles of one mark (s_memtime + its wait)
+        n_marks = [rounds, v[base], v[base], v[base + 2], rounds]  # marks taken per section
+        net = [max(t[base + i] - mark * n_marks[i], 0.0) for i in range(5)]
+        tot = sum(net) or 1.0
+        print(f"{name}: wave cycles by section, the marks' own cost ({mark:.0f} cycles each) taken out: " + ", ".join(f"{n} {100.0 * net[i] / tot:.1f} %" for i, n in enumerate(parts)))
+        print(f"  per round {tot / rounds:.0f} cycles; per visit: {net[1] / max(v[base], 1):.0f} until the record is there, {net[2] / max(v[base], 1):.0f} after; "
+              f"per leaf turn {net[3] / max(v[base + 2], 1):.0f}; round tests {net[4] / rounds:.0f}; refill {net[0] / rounds:.0f} per round")
+        summary["closest" if base == 0 else "shadow"]["wave_cycle_share"] = {n: net[i] / tot for i, n in enumerate(parts)}
+        summary["closest" if base == 0 else "shadow"]["cycles_per_round"] = tot / rounds
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "lane_stats_cornellbox.json"), "w"), indent=1)
 
