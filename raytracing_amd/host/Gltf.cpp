@@ -165,10 +165,11 @@ bool read_file(const std::string& path, std::vector<uint8_t>* out) {
 }
 
 bool base64_decode(const std::string& s, size_t from, std::vector<uint8_t>* out) {
-    int val = 0, bits = -8;
+    uint32_t val = 0; // unsigned: the accumulator is shifted for the whole length of the text, only its low bits are read
+    int bits = -8;
     for (size_t i = from; i < s.size(); i++) {
         unsigned char c = s[i];
-        int d;
+        uint32_t d;
         if (c >= 'A' && c <= 'Z') d = c - 'A';
         else if (c >= 'a' && c <= 'z') d = c - 'a' + 26;
         else if (c >= '0' && c <= '9') d = c - '0' + 52;
