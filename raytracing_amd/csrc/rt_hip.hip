@@ -596,28 +596,31 @@ __global__ __launch_bounds__(RT_BLOCK, TL ? RT_SHADE_WAVES_TL : RT_SHADE_WAVES) 
 
 // radiance += throughput * direct (main.cpp:430), a path's slots summed in reference order (environment ray, then the
 // lights).  One lane per shadow-queue entry; the lane of a path's FIRST ray does the path's sum (its rays are consecutive).
+// Persistent workgroups, as k_classify: workgroup b takes every (gridDim / n_shards)-th RT_BLOCK group of the LIVE entries of
+// shard b % n_shards (a launch at the queue's capacity — 33 M threads at 1080p x 8 spp x 2 rays — spent 0.12 ms per launch
+// on workgroups that found nothing to do, 32 launches per step).
 __global__ __launch_bounds__(RT_BLOCK) void k_nee_resolve(Wave w, PassParams pp, int bounce) {
     memory_bound_priority();
-    const uint32_t j = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t shard = blockIdx.x % pp.n_shards, sub = blockIdx.x / pp.n_shards, n_sub = gridDim.x / pp.n_shards;
     const uint32_t shard_span = (uint32_t)pp.K * pp.shard_cap; // shadow-queue entries reserved per shard
-    const uint32_t shard = j / shard_span;
-    if (shard >= pp.n_shards) return;
     const uint32_t live = w.counts[(size_t)(64u * pp.n_shards + (uint32_t)bounce * pp.n_shards + shard) * RT_CSTRIDE];
-    if (j - shard * shard_span >= live) return;
-    const float4 c0 = w.s_c[j];
-    const int p = (int)__float_as_uint(c0.w) - 1;
-    if (p < 0) return; // not a path's first ray
-    const float4 T4 = w.s_T[j];
-    const uint32_t n = __float_as_uint(T4.w);
-    V3 direct(0.f);
-    if (w.vis[j]) direct = direct + V3(c0);
-    for (uint32_t r = 1; r < n; r++)
-        if (w.vis[j + r]) direct = direct + V3(w.s_c[j + r]);
-    // nothing arrives (every ray blocked, or lights seen from behind): radiance + 0 is radiance (it is never -0: it starts
-    // at +0 and the NaN / inf cases fail this test), so the path record — a random 64-byte sector — is left alone
-    const V3 add = V3(T4) * direct;
-    if (add.x == 0.f && add.y == 0.f && add.z == 0.f) return;
-    w.rad[p] = pack(V3(w.rad[p]) + add, 0.f);
+    for (uint32_t i = sub * RT_BLOCK + threadIdx.x; i < live; i += n_sub * RT_BLOCK) {
+        const uint32_t j = shard * shard_span + i;
+        const float4 c0 = w.s_c[j];
+        const int p = (int)__float_as_uint(c0.w) - 1;
+        if (p < 0) continue; // not a path's first ray
+        const float4 T4 = w.s_T[j];
+        const uint32_t n = __float_as_uint(T4.w);
+        V3 direct(0.f);
+        if (w.vis[j]) direct = direct + V3(c0);
+        for (uint32_t r = 1; r < n; r++)
+            if (w.vis[j + r]) direct = direct + V3(w.s_c[j + r]);
+        // nothing arrives (every ray blocked, or lights seen from behind): radiance + 0 is radiance (it is never -0: it starts
+        // at +0 and the NaN / inf cases fail this test), so the path record — a random 64-byte sector — is left alone
+        const V3 add = V3(T4) * direct;
+        if (add.x == 0.f && add.y == 0.f && add.z == 0.f) continue;
+        w.rad[p] = pack(V3(w.rad[p]) + add, 0.f);
+    }
 }
 
 // pixel_total += s with the NaN guard of main.cpp:984-987, samples in index order
@@ -691,6 +694,7 @@ struct rt_scene {
     int32_t n_materials = 0, n_lights = 0;
     std::vector<int> keys; // material types some triangle uses, most triangles first, then RT_KEY_MISS
     unsigned shade_blocks = 64; // resident workgroups of a shading launch (a multiple of RT_SHARDS)
+    unsigned resolve_blocks = 64; // ... of a k_nee_resolve launch (a streaming kernel: 8 small workgroups per CU)
     std::vector<void*> owned; // scene arrays
     // wavefront buffers: two sets, so that consecutive sample passes of one rt_render call can run on two streams
     Wave wave[RT_MAX_SETS] = {};
@@ -947,6 +951,9 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
             unsigned shade_mult = 4; // resident shading workgroups per CU
             if (const char* e = getenv("RT_TUNE_SHADE_MULT")) shade_mult = (unsigned)std::max(1, std::min(8, atoi(e)));
             s->shade_blocks = std::max((unsigned)RT_SHARDS, ((unsigned)prop.multiProcessorCount * shade_mult) / RT_SHARDS * RT_SHARDS);
+            unsigned resolve_mult = 8;
+            if (const char* e = getenv("RT_TUNE_RESOLVE_MULT")) resolve_mult = (unsigned)std::max(1, std::min(32, atoi(e)));
+            s->resolve_blocks = std::max((unsigned)RT_SHARDS, ((unsigned)prop.multiProcessorCount * resolve_mult) / RT_SHARDS * RT_SHARDS);
             if (const char* e = getenv("RT_TUNE_PERSIST_EIGHTHS")) // traversal grid as eighths of full occupancy
                 s->persistent_blocks = std::max(wg_unit, s->persistent_blocks * (unsigned)std::max(1, std::min(8, atoi(e))) / 8u / wg_unit * wg_unit);
             // several passes in flight: each pass's traversal launches take 3/8 of the wave slots, so the other pass's
@@ -1465,7 +1472,7 @@ static int render_common(rt_scene* s, const rt_camera* cam, const rt_options* o,
                                    shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);
             mark();
             mark();
-            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(blocks_for((int64_t)K * pp.capq)), dim3(RT_BLOCK), 0, st, wave, pp, b);
+            if (K > 0) hipLaunchKernelGGL(k_nee_resolve, dim3(s->resolve_blocks), dim3(RT_BLOCK), 0, st, wave, pp, b);
             mark();
         }
         mark();
