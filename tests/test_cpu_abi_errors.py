@@ -230,3 +230,118 @@ def test_render_refuses_what_does_not_fit_the_gpu(rta, gpu):
     small = rta.camera(rta.look_at((0.0, 1.0, 3.2), (0.0, 1.0, 0.0), (0, 1, 0)), 45.0, 32, 32)
     img, st = sc.render(small, 32, 32, spp=2, max_depth=2)
     assert st["paths"] == 2048
+
+
+def _py_valid(a, root_ref):
+    """An independent statement of what rt_scene_create must accept (include/rt_hip.h): every reference in range, the pair
+    records a tree no deeper than 64 in which every record is reached once, leaves ending at a flagged triangle."""
+    pairs, tris, mats, lights = a["FLAT_PAIRS"], a["FLAT_TRIS"], a["MATERIALS"], a["LIGHTS"]
+    n_p, n_t = len(pairs), len(tris)
+    if not (all(0 <= int(m) < len(mats) for m in tris["material"]) and all(int(l) < len(lights) for l in tris["light"])):  # (any negative light index means "no light")
+        return False
+    if not all(0 <= int(t) < 13 - 1 for t in mats["type"]):  # RT_KEY_MISS = 12: material types are 0..11
+        return False
+    for L in lights:
+        if int(L["kind"]) != 0 or not (0 <= int(L["material"]) < len(mats)):  # RT_LIGHT_RECT in this scene
+            return False
+    if not (int(tris["tri_id"][-1]) & 0x80000000):
+        return False
+
+    def ok_ref(r):
+        return (0 <= r < n_p) if r >= 0 else (0 <= ~r < n_t)
+
+    if not ok_ref(int(root_ref)):
+        return False
+    seen, stack = set(), [(int(root_ref), 1)]
+    while stack:
+        r, depth = stack.pop()
+        if r < 0:
+            continue
+        if r in seen or depth > 64:
+            return False
+        seen.add(r)
+        for c in (int(pairs["lref"][r]), int(pairs["rref"][r])):
+            if not ok_ref(c):
+                return False
+            stack.append((c, depth + 1))
+    return True
+
+
+def test_fuzzed_references_are_refused_or_harmless(rta):
+    """400 random single-word corruptions of a valid description (child refs, material / light indices, leaf flags, material
+    types, light records, the root): the call returns an error code, or — when an independent checker finds the description
+    still valid — what a valid description returns.  It never accepts what the checker refuses: a kernel follows every one
+    of these words."""
+    rng = np.random.default_rng(20260211)
+    sc, a0, d0 = _flat(rta)
+    rc, _ = _create(rta, d0)
+    assert _good(rta, rc) and _py_valid(a0, d0.root_ref)
+    targets = [("FLAT_PAIRS", "lref"), ("FLAT_PAIRS", "rref"), ("FLAT_TRIS", "material"), ("FLAT_TRIS", "light"), ("FLAT_TRIS", "tri_id"),
+               ("MATERIALS", "type"), ("LIGHTS", "kind"), ("LIGHTS", "material"), (None, "root_ref")]
+    refused = 0
+    for it in range(400):
+        sc2, a, d = _flat(rta) if it % 50 == 0 else (sc2, a, d)  # a fresh description now and then; restored below otherwise
+        arr, field = targets[int(rng.integers(len(targets)))]
+        kind = int(rng.integers(4))
+        n_p, n_t = len(a["FLAT_PAIRS"]), len(a["FLAT_TRIS"])
+        value = [int(rng.integers(-2 ** 31, 2 ** 31 - 1)), int(rng.integers(-n_t - 2, n_p + 2)), int(rng.integers(0, 16)), -1][kind]
+        if arr is None:
+            old = d.root_ref
+            d.root_ref = int(np.int32(value))
+        else:
+            i = int(rng.integers(len(a[arr])))
+            old = a[arr][field][i].copy()
+            a[arr][field][i] = np.array(value).astype(np.int64).astype(a[arr][field].dtype)
+        rc, msg = _create(rta, d)
+        valid = _py_valid(a, d.root_ref)
+        assert rc in (RT_OK, RT_ERR_INVALID, RT_ERR_LIMIT, RT_ERR_NO_DEVICE), (rc, msg)
+        if _good(rta, rc):
+            assert valid, f"accepted a description the checker refuses: {arr}.{field} <- {value}"
+        else:
+            refused += 1
+        if arr is None:
+            d.root_ref = old
+        else:
+            a[arr][field][i] = old
+    assert refused > 200
+
+
+def test_fuzzed_two_level_references_are_refused_or_harmless(rta):
+    """The same for rt_scene_create_instanced: TLAS child refs (leaves name instances), an instance's geometry kind,
+    material and blas_root.  Out-of-range values must come back as error codes; values the independent range check allows
+    may be accepted."""
+    rng = np.random.default_rng(77)
+    sc, a, d, t = _two_level(rta)
+    rc, msg = _create(rta, d, t)
+    assert _good(rta, rc), msg
+    n_inst, n_tp, n_p, n_t, n_m = len(a["INSTANCES"]), len(a["TLAS_PAIRS"]), len(a["FLAT_PAIRS"]), len(a["FLAT_TRIS"]), len(a["MATERIALS"])
+
+    def in_range():
+        for r in list(a["TLAS_PAIRS"]["lref"]) + list(a["TLAS_PAIRS"]["rref"]):
+            r = int(r)
+            if not ((0 <= r < n_tp) if r >= 0 else (0 <= ~r < n_inst)):
+                return False
+        for I in a["INSTANCES"]:
+            g, m, b = int(I["geometry"]), int(I["material"]), int(I["blas_root"])
+            if not (0 <= g <= 5 and 0 <= m < n_m):
+                return False
+            if g == 0 and not ((0 <= b < n_p) if b >= 0 else (0 <= ~b < n_t)):
+                return False
+        return True
+
+    targets = [("TLAS_PAIRS", "lref"), ("TLAS_PAIRS", "rref"), ("INSTANCES", "geometry"), ("INSTANCES", "material"), ("INSTANCES", "blas_root")]
+    refused = 0
+    for it in range(300):
+        arr, field = targets[int(rng.integers(len(targets)))]
+        value = [int(rng.integers(-2 ** 31, 2 ** 31 - 1)), int(rng.integers(-n_t - 2, n_p + 2)), int(rng.integers(0, 16)), -1][int(rng.integers(4))]
+        i = int(rng.integers(len(a[arr])))
+        old = a[arr][field][i].copy()
+        a[arr][field][i] = np.array(value).astype(np.int64).astype(np.int32)
+        rc, msg = _create(rta, d, t)
+        assert rc in (RT_OK, RT_ERR_INVALID, RT_ERR_LIMIT, RT_ERR_NO_DEVICE), (rc, msg)
+        if _good(rta, rc):
+            assert in_range(), f"accepted an out-of-range reference: {arr}.{field}[{i}] <- {value}"
+        else:
+            refused += 1
+        a[arr][field][i] = old
+    assert refused > 100
