@@ -1083,7 +1083,7 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
     s->view.tris = (const float4*)tris;
     s->view.normals = (const float4*)normals;
     s->view.root_ref = d->root_ref >= 0 ? d->root_ref * RT_PAIR_BYTES : d->root_ref;
-    s->view.refill_min = 16;
+    s->view.refill_min = 12; // (round 2, after the visits got cheaper in scalar work: 16: k_shadow 38.2 ms per step, 12: 37.6, 8: 37.5 with k_closest +1 %)
     {
         // leaves are tested once this many lanes wait at one: 16 for one-triangle leaves; longer leaf turns (trees built with
         // max_per_node 2: 1.5 triangles per leaf on cornellbox) are worth waiting for more lanes (16: 7.02, 24: 7.09, 28: 7.13 Grays/s)
