@@ -50,7 +50,10 @@ if hasattr(lib, "rt_debug_walk_times"):
         n_marks = [rounds, v[base], v[base], v[base + 2], rounds]  # marks taken per section
         net = [max(t[base + i] - mark * n_marks[i], 0.0) for i in range(5)]
         tot = sum(net) or 1.0
-        print(f"{name}: wave cycles by section, the marks' own cost ({mark:.0f} cycles each) taken out: " + ", ".join(f"{n} {100.0 * net[i] / tot:.1f} %" for i, n in enumerate(parts)))
+        # caveat: the -DRT_STATS build keeps its counters in registers (> 64 VGPRs: half the resident waves of the shipped
+        # walks) and every mark is an s_memtime read whose wait joins the section it closes: shares are indicative, the
+        # lane counts above are exact
+        print(f"{name}: wave cycles by section (indicative: instrumented build at half the shipped occupancy): " + ", ".join(f"{n} {100.0 * net[i] / tot:.1f} %" for i, n in enumerate(parts)))
         print(f"  per round {tot / rounds:.0f} cycles; per visit: {net[1] / max(v[base], 1):.0f} until the record is there, {net[2] / max(v[base], 1):.0f} after; "
               f"per leaf turn {net[3] / max(v[base + 2], 1):.0f}; round tests {net[4] / rounds:.0f}; refill {net[0] / rounds:.0f} per round")
         summary["closest" if base == 0 else "shadow"]["wave_cycle_share"] = {n: net[i] / tot for i, n in enumerate(parts)}
