@@ -293,7 +293,8 @@ int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* tmax, int64_t
                  uint8_t* occluded);
 
 /* rt_trace_closest for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
- * call hipMalloc — code under HIP graph capture, tight serving loops, harnesses that forbid allocation.  Same walk, same
+ * call hipMalloc — tight serving loops, harnesses that forbid allocation, code that sets up HIP graph capture around its OWN
+ * streams (the call itself synchronises the scene's stream and asks for pointer attributes: it cannot run INSIDE a capture).  Same walk, same
  * kernels and same results as rt_trace_closest, but `rays` and `hits` are DEVICE pointers on the scene's GPU (hits
  * 16-byte aligned; a miss is tri = -1, t = inf, u = v = 0) and the walk's scratch (two float4 ray streams, shard counters
  * and fetch cursors, the second hit record of two-level scenes) is a static device array of the library: 24 MiB + 16 KiB

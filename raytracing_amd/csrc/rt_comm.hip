@@ -53,7 +53,8 @@ Rccl* rccl() { // loaded once; nullptr-lib + error text when it cannot be
         for (const char* n : names)
             if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!r.lib) {
-            r.error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found");
+            const char* e = dlerror(); // one call: dlerror() hands the message out once and clears it
+            r.error = std::string("cannot load librccl: ") + (e ? e : "not found");
             return;
         }
         bool ok = true;
@@ -85,7 +86,9 @@ struct SharedDevice {
     uint64_t generation = 0;
     std::vector<float*> bufs;
     size_t n = 0;
-    int status = RT_OK;
+    int status = RT_OK;       // of the round being gathered
+    int done_status = RT_OK;  // of the round that finished last: what that round's waiters read (a faster rank may already
+                              // have opened the next round and reset `status`)
 };
 
 __global__ __launch_bounds__(256) void k_add_into(float* __restrict__ dst, const float* __restrict__ src, size_t n) {
@@ -243,13 +246,15 @@ int rt_reduce(rt_comm* c, float* buf, size_t n, int root) {
             }
             if (hipStreamSynchronize(c->stream) != hipSuccess) sh.status = RT_ERR_HIP;
         }
+        sh.done_status = sh.status;
         sh.arrived = 0;
         sh.generation++;
         sh.cv.notify_all();
     } else {
+        // (a waiter leaves with the mutex held before any rank can finish the NEXT round: that round needs this rank too)
         sh.cv.wait(lock, [&] { return sh.generation != gen; });
     }
-    const int status = sh.status;
+    const int status = sh.done_status;
     lock.unlock();
     if (status == RT_ERR_INVALID) return rt_fail_message(status, "rt_reduce: ranks passed different element counts");
     if (status != RT_OK) return rt_fail_message(status, "rt_reduce: the shared-device add failed");

@@ -719,6 +719,7 @@ struct rt_scene {
     size_t d_tiles_cap = 0;
     std::vector<int32_t> tiles_host; // x0, y0, x1, y1 per tile, as the caller gave them
     int64_t tiles_npix = 0;
+    int32_t tiles_w = 0, tiles_h = 0; // raster the cached list was checked against
 };
 
 template <typename T>
@@ -1291,8 +1292,10 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit*
 
 // Checks a tile list (rectangles inside the raster, not empty, pairwise disjoint) and puts its device table in place.
 static int set_tiles(rt_scene* s, const rt_options* o, const int32_t* tiles, int32_t n_tiles) {
-    if (s->tiles_host.size() == (size_t)4 * n_tiles && std::memcmp(s->tiles_host.data(), tiles, sizeof(int32_t) * 4 * (size_t)n_tiles) == 0 && s->d_tiles)
-        return RT_OK; // the list of the previous call
+    // the list of the previous call, on the raster it was checked against (the same list on a smaller raster may leave it)
+    if (s->tiles_host.size() == (size_t)4 * n_tiles && s->tiles_w == o->width && s->tiles_h == o->height && s->d_tiles &&
+        std::memcmp(s->tiles_host.data(), tiles, sizeof(int32_t) * 4 * (size_t)n_tiles) == 0)
+        return RT_OK;
     std::vector<int4> tab((size_t)n_tiles);
     int64_t first = 0;
     for (int32_t k = 0; k < n_tiles; k++) {
@@ -1324,6 +1327,8 @@ static int set_tiles(rt_scene* s, const rt_options* o, const int32_t* tiles, int
     s->tiles_host.clear();
     HIPCHK(hipMemcpy(s->d_tiles, tab.data(), sizeof(int4) * (size_t)n_tiles, hipMemcpyHostToDevice));
     s->tiles_host.assign(tiles, tiles + 4 * (size_t)n_tiles);
+    s->tiles_w = o->width;
+    s->tiles_h = o->height;
     s->tiles_npix = first;
     return RT_OK;
 }

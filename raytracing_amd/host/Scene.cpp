@@ -689,6 +689,10 @@ void Renderer::initalize(const Options& options) { // main.cpp:936-948
 }
 
 void shard_sample_window(int rank, int world, int spp, int* begin, int* count) {
+    if (world < 1 || rank < 0 || rank >= world || spp < 0) { // (a caller's mistake must not become a division by zero)
+        *begin = *count = 0;
+        return;
+    }
     const int base = spp / world, extra = spp % world; // the first `extra` ranks take one sample more
     *begin = rank * base + (rank < extra ? rank : extra);
     *count = base + (rank < extra ? 1 : 0);
@@ -696,6 +700,7 @@ void shard_sample_window(int rank, int world, int spp, int* begin, int* count) {
 
 std::vector<int32_t> shard_tiles(int rank, int world, int width, int height, int tile) {
     std::vector<int32_t> out;
+    if (world < 1 || rank < 0 || rank >= world || tile < 1 || width < 1 || height < 1) return out; // world 0 would loop for ever, tile 0 divide by zero
     const int tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile;
     for (int t = rank; t < tx * ty; t += world) { // row-major tile index, as TileQueue counts (main.cpp:914-928)
         const int x0 = (t % tx) * tile, y0 = (t / tx) * tile;
@@ -732,9 +737,19 @@ bool Renderer::render_sharded(const Camera& cam, const Scene& scene, const Optio
     std::vector<rt_stats> stats((size_t)G);
     std::vector<std::string> errors((size_t)G);
     const rt_camera c = cam.flatten();
+    // Every frame is allocated HERE, before any rank starts: a rank that left early (no frame) would never reach rt_reduce, and
+    // the others would wait for it in the collective for ever.
+    for (int r = 0; r < G; r++)
+        if (rt_buffer_alloc(options.devices[(size_t)r], n * sizeof(float), &frames[(size_t)r]) != RT_OK) {
+            std::printf("Renderer: rank %d (device %d): %s\n", r, options.devices[(size_t)r], rt_last_error());
+            for (int k = 0; k < G; k++) {
+                rt_buffer_free(options.devices[(size_t)k], frames[(size_t)k]);
+                rt_comm_destroy(comms[(size_t)k]);
+            }
+            return false;
+        }
     auto rank_main = [&](int r) {
         auto failed = [&]() { errors[(size_t)r] = rt_last_error(); };
-        if (rt_buffer_alloc(options.devices[(size_t)r], n * sizeof(float), &frames[(size_t)r]) != RT_OK) return failed();
         rt_options o{};
         o.width = width;
         o.height = height;

@@ -268,6 +268,19 @@ def test_sharding_helpers():
         sharding.sample_window(4, 4, 1)
 
 
+def test_host_partitions_refuse_nonsense(rta):
+    """rth_shard_tiles / rth_shard_sample_window with world 0, a rank outside the world or a zero tile edge return nothing
+    (world 0 used to loop for ever, tile 0 to divide by zero)."""
+    assert len(rta.shard_tiles(0, 0, 64, 64, 16)) == 0
+    assert len(rta.shard_tiles(2, 2, 64, 64, 16)) == 0
+    assert len(rta.shard_tiles(-1, 2, 64, 64, 16)) == 0
+    assert len(rta.shard_tiles(0, 1, 64, 64, 0)) == 0
+    assert len(rta.shard_tiles(0, 1, 64, 64, 16)) == 16
+    assert rta.shard_sample_window(0, 0, 64) == (0, 0)
+    assert rta.shard_sample_window(3, 2, 64) == (0, 0)
+    assert rta.shard_sample_window(1, 2, 65) == (33, 32)
+
+
 def test_add_instance_flattens_with_the_reference_transform(rta):
     """Scene::add_instance = Instance(TriangleMesh, material, transform) flattened: positions through the matrix,
     normals through the normalised inverse transpose (Object.h:388-391); identity = add_mesh."""

@@ -47,6 +47,12 @@ def test_render_tiles_is_render(rta, room):
         room.render(cam, w, h, spp=1, max_depth=2, tiles=[(0, 0, 20, 20), (90, 60, 101, 70)])
     with pytest.raises(rta.RtError, match="empty"):
         room.render(cam, w, h, spp=1, max_depth=2, tiles=np.zeros((0, 4), np.int32))
+    # the cached list is only good for the raster it was checked against: the same list on a smaller raster is refused
+    # (it used to pass as "the list of the previous call" and write beyond the rows of the smaller frame)
+    room.render(cam, w, h, spp=1, max_depth=2, tiles=tiles)
+    small = rta.camera(rta.look_at(*VIEW), 45.0, w - 20, h - 10)
+    with pytest.raises(rta.RtError, match="bad tile"):
+        room.render(small, w - 20, h - 10, spp=1, max_depth=2, tiles=tiles)
 
 
 def _mask_outside(tiles, w, h):
