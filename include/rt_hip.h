@@ -292,6 +292,12 @@ int rt_trace_closest_indexed(rt_scene* scene, const rt_ray* rays, int64_t n, rt_
 int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* tmax, int64_t n,
                  uint8_t* occluded);
 
+/* How the scene's occlusion queries (rt_trace_any, the shadow rays of rt_render) walk the tree: 0 = the child-pair records
+ * (the default), n > 0 = n compressed four-wide records built from the same pairs (RT_TUNE_QUADS=1 in the environment of
+ * rt_scene_create; DESIGN.md section 4: same flags bit for bit, measured slower on the headline workload).  No counterpart
+ * in the reference (its trace_scene has one walk, Object.h:273-344). */
+int64_t rt_scene_quad_records(const rt_scene* scene);
+
 /* rt_trace_closest for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
  * call hipMalloc — tight serving loops, harnesses that forbid allocation, code that sets up HIP graph capture around its OWN
  * streams (the call itself synchronises the scene's stream and asks for pointer attributes: it cannot run INSIDE a capture).  Same walk, same

@@ -85,7 +85,7 @@ HIP_SYMBOLS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_
                "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_render_tiles",
                "rt_resolve", "rt_scene_sync", "rt_comm_unique_id", "rt_comm_create", "rt_comm_create_local", "rt_comm_rank",
                "rt_comm_world", "rt_reduce", "rt_comm_destroy", "rt_buffer_alloc", "rt_buffer_download", "rt_buffer_zero",
-               "rt_buffer_free"]
+               "rt_buffer_free", "rt_scene_quad_records"]
 NOALLOC_MAX_RAYS = 1 << 19
 
 
@@ -120,6 +120,8 @@ def load_libraries():
     hip.rt_comm_destroy.restype = None
     hip.rt_resolve.argtypes = [vp, vp, i32, i32, i32, f32, vp]
     hip.rt_scene_sync.argtypes = [vp]
+    hip.rt_scene_quad_records.argtypes = [vp]
+    hip.rt_scene_quad_records.restype = i64
     host.rth_bvh_build.argtypes = [vp, i32, i32, i32, vp, vp]
     host.rth_bvh_build.restype = i32
     host.rth_scene_new.restype = vp
@@ -490,6 +492,10 @@ class Scene:
         return g
 
     # ---- GPU calls (straight through the C-ABI of include/rt_hip.h)
+    def quad_records(self):
+        """rt_scene_quad_records: 0 = occlusion queries walk the pair records, n = the compressed four-wide records."""
+        return int(_hip.rt_scene_quad_records(self.gpu))
+
     def trace_closest(self, rays):
         rays = np.ascontiguousarray(rays, dtype=RAY)
         hits = np.zeros(len(rays), HIT)

@@ -111,6 +111,12 @@ struct SceneView {
     int32_t wave_min_rays; // a shard of n rays is worked on by at most ceil(n / wave_min_rays) waves
     int32_t fetch_chunk;   // rays a wave takes from its shard per cursor atomic (multiple of 64)
     // legacy two-level scenes (inst_q != nullptr): instances, k_classify's sort key per instance
+    // compressed four-wide records of the SAME tree for the occlusion walks (see "four-wide occlusion walk" below); nullptr:
+    // the scene walks pair records everywhere (the default: see rt_scene_create; also boxes that do not nest, trees too deep for the quad stack)
+    const float4* onodes;  // 4 x float4 per record: quad records, then one leaf record per triangle slot
+    int32_t qroot;         // ref of the root quad record
+    int32_t n_quads;
+    int32_t leaf_base;     // byte offset of slot 0's leaf record
     const float4* inst_q;  // RT_INST_QUADS float4 per instance (see "two-level scenes" below); the TLAS records lead `pairs`
     const float4* inst_p;  // 3 float4 per instance: rt_instance.p
     const uint8_t* inst_type;
@@ -652,6 +658,285 @@ RT_DEV void occlusion_queue(const SceneView& sc, const float4* __restrict__ q_o,
                     if (sp < RT_SHORT_STACK) cur = lds[sp * RT_TRAV_BLOCK];
                     else cur = spill[sp - RT_SHORT_STACK];
                 }
+            }
+            if (cur == RT_CUR_FINISH || cur == RT_CUR_HIT) {
+                sink(q, tag, cur == RT_CUR_HIT);
+                cur = RT_CUR_DONE;
+                exact = false;
+            }
+        }
+        RT_TWAIT;
+        RT_TMARK(3);
+    }
+    RT_STAT_FLUSH(8);
+    RT_TFLUSH(8);
+}
+
+// ------------------------------------------------ four-wide occlusion walk
+// The boolean answer of trace_scene (Scene.h:113-129 as used at main.cpp:250,281; the walk is Object.h:322-343) is "some
+// triangle in a REACHED leaf is accepted", and the set of reached leaves does not depend on how the walk gets to them:
+//   (1) a parent's box is the componentwise min / max of its children's boxes (rt_scene_create checks that every box lies
+//       inside its parent's before it builds the records below);
+//   (2) the slab test is MONOTONE in the box: fl(b - o) is non-decreasing in b and fl(y * inv) is monotone in y for a
+//       finite non-zero inv, so for boxes C containing B (as fp32 numbers, per component) tnear(C) <= tnear(B) and
+//       tfar(C) >= tfar(B) hold IN fp32 — whenever B passes `!(tnear > tfar || tfar < 0) && tnear < tcull`, C does;
+//   (3) so a leaf whose own box passes has every ancestor passing: the binary walk reaches a leaf iff the leaf's OWN box
+//       passes, whatever the order.
+// The occlusion walks therefore use a four-wide collapse of the tree (the inner child with the largest surface is opened
+// until a record holds four children) whose child boxes are CONSERVATIVE 8-bit boxes on a grid of the record's own extent
+// (each decoded plane is verified on the host, with the device's arithmetic, to lie on or outside the exact plane): by (2)
+// the walk reaches a superset of the leaves the reference reaches, and every leaf record carries its EXACT box — the one
+// the reference tests before it enters the leaf (Object.h:325-326) — which is tested, with the binary walk's own
+// arithmetic, before the leaf's triangles are.  By (3) that single test decides reached / not reached as the reference
+// does: same flags, bit for bit, at a quarter of the bytes per child and less than half the dependent visits per ray.  (The
+// measured reason for the format: the walks are bound by the LDS / vector-L1 transactions a visit makes — uncompressed
+// 128-byte quad records halved the visits, doubled the cost of each, and changed nothing.)
+// Rays that need the select-form slab test (`exact`: non-finite 1/dir or origin, where NaNs void (2)) walk the PAIR
+// records in the same loop with the same stack.
+//
+// One buffer of 64-byte records ("onodes"), quad records first (top of the tree first), then one leaf record per triangle
+// slot.  A ref is the record's byte offset, bit 0 set for a leaf record, bit 1 for "box already tested" (refs of the pair
+// walk's lanes).
+//   quad record (16 words):  [0..2] origin  [3] biased exponents of the grid steps, x | y << 8 | z << 16
+//     [4] lo.x of children 0..3 (one byte each)  [5] lo.y  [6] lo.z  [7] hi.x  [8] hi.y  [9] hi.z
+//     [10..13] child refs (RT_REF_NONE: no child; a record holds 2 to 4, empty slots last)  [14..15] spare
+//     plane = fma(q, step, origin): lo planes <= the exact min, hi planes >= the exact max
+//   leaf record (16 words):  [0..5] exact box min, max of the LEAF (first triangle's record only)
+//     [6..8] v0  [9..11] e1  [12..14] e2 (Object.h:247-248)  [15] bit 0: last triangle of its leaf
+// Quad records [0, RT_QTOP) are read from LDS, kept there as FOUR part arrays (see load_pair).
+#define RT_ONODE_BYTES 64
+#ifndef RT_QTOP
+#define RT_QTOP 256
+#endif
+#define RT_QTOP_PART_BYTES (RT_QTOP * 16)
+#define RT_QTOP_LDS_BYTES (RT_QTOP * 56)
+#ifndef RT_QSHORT_STACK
+#define RT_QSHORT_STACK 12  // stack entries per lane in LDS (a visit pushes up to three: 8: 43.1, 12: 41.8, 16: 41.9 ms per step)
+#endif
+#define RT_QSTACK_TOTAL 96  // rt_scene_create computes a tree's worst case and keeps a deeper one on the pair walk
+#define RT_REF_NONE ((int)0x80000000)
+#define RT_REF_LEAF 1
+#define RT_REF_TESTED 2
+
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u4 lds_cu4;
+
+RT_DEV void load_quad(const float4* __restrict__ onodes, lds_cf4* top, int top_bytes, int cur, u4& w0, u4& w1, u4& w2, int& r2, int& r3) {
+    if (cur < top_bytes) {
+        const __attribute__((address_space(3))) char* base = (const __attribute__((address_space(3))) char*)top;
+        const uint32_t at = (uint32_t)cur >> 2; // record index * 16
+        w0 = *(lds_cu4*)(base + at);
+        w1 = *(lds_cu4*)(base + at + RT_QTOP_PART_BYTES);
+        w2 = *(lds_cu4*)(base + at + 2 * RT_QTOP_PART_BYTES);
+        const unsigned long long rr = *(const __attribute__((address_space(3))) unsigned long long*)(base + ((uint32_t)cur >> 3) + 3 * RT_QTOP_PART_BYTES);
+        r2 = (int)(uint32_t)rr;
+        r3 = (int)(uint32_t)(rr >> 32);
+    } else {
+        const u4* p = (const u4*)((const char*)onodes + (uint32_t)cur);
+        w0 = p[0];
+        w1 = p[1];
+        w2 = p[2];
+        const unsigned long long rr = *(const unsigned long long*)(p + 3);
+        r2 = (int)(uint32_t)rr;
+        r3 = (int)(uint32_t)(rr >> 32);
+    }
+}
+
+// byte k of w as a float (v_cvt_f32_ubyte<k>)
+template <int K>
+RT_DEV float ubyte(uint32_t w) { return (float)((w >> (8 * K)) & 0xffu); }
+
+// Child K of a quad record against the ray: its six decoded planes, then the slab arithmetic of Bounds::intersect
+// (Math.h:757-770) in the form slab_pair gives it.  One child at a time: six plane words, twelve temporaries and the four
+// entry distances are all a visit holds (the per-axis form kept 24 distances live and did not fit 64 registers).
+struct QuadGrid {
+    float sx, sy, sz, gx, gy, gz; // grid steps and origin
+};
+template <int K>
+RT_DEV float quad_child(const u4& w1, const u4& w2, const QuadGrid& g, const V3& o, const V3& inv, float tcull, bool& hit) {
+    const float ax = (__builtin_fmaf(ubyte<K>(w1.x), g.sx, g.gx) - o.x) * inv.x, bx = (__builtin_fmaf(ubyte<K>(w1.w), g.sx, g.gx) - o.x) * inv.x;
+    const float ay = (__builtin_fmaf(ubyte<K>(w1.y), g.sy, g.gy) - o.y) * inv.y, by = (__builtin_fmaf(ubyte<K>(w2.x), g.sy, g.gy) - o.y) * inv.y;
+    const float az = (__builtin_fmaf(ubyte<K>(w1.z), g.sz, g.gz) - o.z) * inv.z, bz = (__builtin_fmaf(ubyte<K>(w2.y), g.sz, g.gz) - o.z) * inv.z;
+    const float tn = vmax3(vmin(ax, bx), vmin(ay, by), vmin(az, bz));
+    const float tf = vmin3(vmax(ax, bx), vmax(ay, by), vmax(az, bz));
+    hit = !(tn > tf || tf < 0.f) && tn < tcull;
+    return tn;
+}
+
+// compare-exchange of two (distance, ref) pairs: afterwards ka <= kb
+RT_DEV void order2(float& ka, int& ra, float& kb, int& rb) {
+    const bool sw = kb < ka;
+    const float k = sw ? kb : ka;
+    const int r = sw ? rb : ra;
+    kb = sw ? ka : kb;
+    rb = sw ? ra : rb;
+    ka = k;
+    ra = r;
+}
+
+// The exact box of a leaf against the ray, as slab_pair<false> computes it for a child of a pair record (same operations
+// on the same operands: v_max3 / v_min3 do not depend on operand order for non-NaN inputs).
+RT_DEV bool leaf_box_passes(const f4& r0, const f4& r1, const V3& o, const V3& inv, float tcull) {
+    const float ax = (r0.x - o.x) * inv.x, ay = (r0.y - o.y) * inv.y, az = (r0.z - o.z) * inv.z;
+    const float bx = (r0.w - o.x) * inv.x, by = (r1.x - o.y) * inv.y, bz = (r1.y - o.z) * inv.z;
+    const float tn = vmax3(vmin(ax, bx), vmin(ay, by), vmin(az, bz));
+    const float tf = vmin3(vmax(ax, bx), vmax(ay, by), vmax(az, bz));
+    return !(tn > tf || tf < 0.f) && tn < tcull;
+}
+
+// occlusion_queue over the onode records.  sink as there.  leaf_base: byte offset of slot 0's leaf record.
+template <class Sink>
+RT_DEV void occlusion_queue4(const SceneView& sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                             const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
+                             lds_int* lds, lds_cf4* top, int top_bytes, Sink sink) {
+    int spill[RT_QSTACK_TOTAL - RT_QSHORT_STACK];
+    V3 o(0.f), d(0.f), inv(0.f); // (origin and 1/dir as scalars: the pair walk's register pairs are rebuilt where the rare
+                                 // select-form ray needs them)
+    float tmax = 0.f, tcull = 0.f;
+    uint32_t q = 0, tag = 0;
+    bool exact = false;
+    int cur = RT_CUR_DONE, sp = 0;
+    const float4* __restrict__ pairs = sc.pairs;
+    const float4* __restrict__ onodes = sc.onodes;
+    const int leaf_base = sc.leaf_base;
+    RT_STAT_DECL
+    RT_TDECL
+    auto push = [&](int v) {
+        if (sp < RT_QSHORT_STACK) lds[sp * RT_TRAV_BLOCK] = v;
+        else if (sp < RT_QSTACK_TOTAL) spill[sp - RT_QSHORT_STACK] = v;
+        if (sp < RT_QSTACK_TOTAL) sp++; // (rt_scene_create keeps deeper trees off this walk; were one to get here, the entry is lost, never memory)
+    };
+    auto pop = [&]() {
+        if (sp == 0) return RT_CUR_FINISH;
+        sp--;
+        return sp < RT_QSHORT_STACK ? (int)lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_QSHORT_STACK];
+    };
+    // a pair-walk ref (exact rays) as an onode ref: leaves become leaf records whose box the pair walk has tested
+    auto pair_ref = [&](int r) { return r >= 0 ? r : (leaf_base + (~r) * RT_ONODE_BYTES) | RT_REF_LEAF | RT_REF_TESTED; };
+    QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
+    for (;;) {
+        if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
+            uint32_t idx;
+            if (queue_fetch(qs, cur == RT_CUR_DONE, &idx)) {
+                const float4 o4 = q_o[idx], d4 = q_d[idx];
+                q = idx;
+                tag = __float_as_uint(d4.w);
+                o = V3(o4);
+                d = V3(d4);
+                const RaySlab rs = ray_slab(o4, d4, &exact);
+                inv = V3(rs.ixy.x, rs.ixy.y, rs.izz.x);
+                tmax = o4.w;
+                tcull = (tmax > 0.f && tmax < INFINITY) ? tmax * 1.0001f + 0.000001f : (tmax <= 0.f ? tmax : INFINITY);
+                sp = 0;
+                cur = exact ? pair_ref(sc.root_ref) : sc.qroot;
+            }
+        }
+        RT_TMARK(0);
+        RT_TMARK(5);
+        if (__ballot(cur != RT_CUR_DONE) == 0ull) break;
+        RT_STAT(3, cur != RT_CUR_DONE);
+#pragma unroll
+        for (int rep = 0; rep < RT_OCC_STEPS; rep++) {
+            const bool inner = cur >= 0 && !(cur & RT_REF_LEAF);
+            RT_STAT(0, inner);
+            RT_STAT(2, inner && cur < top_bytes && !exact);
+            if (inner && !exact) {
+                u4 w0, w1, w2;
+                int r0, r1, r2, r3;
+                load_quad(onodes, top, top_bytes, cur, w0, w1, w2, r2, r3);
+                RT_TWAIT;
+                RT_TMARK(1);
+                r0 = (int)w2.z;
+                r1 = (int)w2.w;
+                QuadGrid g;
+                g.sx = __uint_as_float((w0.w & 0xffu) << 23);
+                g.sy = __uint_as_float((w0.w & 0xff00u) << 15);
+                g.sz = __uint_as_float((w0.w & 0xff0000u) << 7);
+                g.gx = __uint_as_float(w0.x);
+                g.gy = __uint_as_float(w0.y);
+                g.gz = __uint_as_float(w0.z);
+                bool h0, h1, h2, h3;
+                float k0 = quad_child<0>(w1, w2, g, o, inv, tcull, h0);
+                float k1 = quad_child<1>(w1, w2, g, o, inv, tcull, h1);
+                float k2 = quad_child<2>(w1, w2, g, o, inv, tcull, h2);
+                float k3 = quad_child<3>(w1, w2, g, o, inv, tcull, h3);
+                h2 = h2 && r2 != RT_REF_NONE;
+                h3 = h3 && r3 != RT_REF_NONE;
+                RT_PROBE_STEP(k0);
+                const int n = (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+                k0 = h0 ? k0 : INFINITY; // (a hit has k < tcull <= inf: misses sort behind every hit)
+                k1 = h1 ? k1 : INFINITY;
+                k2 = h2 ? k2 : INFINITY;
+                k3 = h3 ? k3 : INFINITY;
+                order2(k0, r0, k1, r1);
+                order2(k2, r2, k3, r3);
+                order2(k0, r0, k2, r2);
+                order2(k1, r1, k3, r3);
+                order2(k1, r1, k2, r2);
+                // nearest child next, the others on the stack with the nearer ones on top (near first as Object.h:328-337
+                // has it; the answer does not depend on the order)
+                if (__ballot(sp > RT_QSHORT_STACK - 3) == 0ull) { // wave-uniform: nobody can leave the LDS part
+                    if (n == 4) lds[sp * RT_TRAV_BLOCK] = r3;
+                    if (n >= 3) lds[(sp + n - 3) * RT_TRAV_BLOCK] = r2;
+                    if (n >= 2) lds[(sp + n - 2) * RT_TRAV_BLOCK] = r1;
+                    const bool take = n == 0 && sp > 0;
+                    int next = RT_CUR_FINISH;
+                    if (take) next = lds[(sp - 1) * RT_TRAV_BLOCK];
+                    cur = n == 0 ? next : r0;
+                    sp += (n > 0 ? n - 1 : 0) - (take ? 1 : 0);
+                } else {
+                    if (n == 4) push(r3);
+                    if (n >= 3) push(r2);
+                    if (n >= 2) push(r1);
+                    cur = n == 0 ? pop() : r0;
+                }
+                RT_TWAIT;
+                RT_TMARK(2);
+            } else if (inner) { // select-form rays: the binary walk of occlusion_queue on the pair records
+                f4 q0, q1, q2;
+                int lref, rref;
+                load_pair(pairs, top, 0, cur, q0, q1, q2, lref, rref);
+                float ld, rd;
+                bool lh, rh;
+                RaySlab rs;
+                rs.oxy = f2{o.x, o.y};
+                rs.ozz = f2{o.z, o.z};
+                rs.ixy = f2{inv.x, inv.y};
+                rs.izz = f2{inv.z, inv.z};
+                slab_pair<true>(q0, q1, q2, rs, ld, lh, rd, rh);
+                lh = lh && ld < tcull;
+                rh = rh && rd < tcull;
+                const bool left_first = ld < rd;
+                cur = pair_ref((lh && (!rh || left_first)) ? lref : rref);
+                if (lh && rh) push(pair_ref(left_first ? rref : lref));
+                else if (!lh && !rh) cur = pop();
+            }
+        }
+        const unsigned long long at_leaf = __ballot(cur >= 0 ? (cur & RT_REF_LEAF) != 0 : cur == RT_CUR_FINISH);
+        if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0 && !(cur & RT_REF_LEAF)) != 0ull) {
+            RT_TMARK(4);
+            continue;
+        }
+        RT_TMARK(4);
+        if (cur >= 0 ? (cur & RT_REF_LEAF) != 0 : cur == RT_CUR_FINISH) {
+            if (cur != RT_CUR_FINISH) {
+                bool test_box = !(cur & RT_REF_TESTED);
+                uint32_t at = (uint32_t)cur & ~3u;
+                bool last, stop = false;
+                RT_STAT(1, true);
+                do {
+                    const f4* p = (const f4*)((const char*)onodes + at);
+                    const f4 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+                    asm volatile("" ::"v"(r0.x), "v"(r1.x), "v"(r2.x), "v"(r3.x)); // (all four requested before the first is used)
+                    last = (__float_as_uint(r3.w) & 1u) != 0u;
+                    if (test_box && !leaf_box_passes(r0, r1, o, inv, tcull)) break; // the reference never enters this leaf
+                    test_box = false;
+                    float tt, u, v;
+                    if (tri_accept(o, d, make_float4(r1.z, r1.w, r2.x, 0.f), make_float4(r2.y, r2.z, r2.w, 0.f), make_float4(r3.x, r3.y, r3.z, 0.f), tmax, &tt, &u, &v))
+                        stop = last = true;
+                    at += RT_ONODE_BYTES;
+                } while (!last);
+                cur = stop ? RT_CUR_HIT : pop();
             }
             if (cur == RT_CUR_FINISH || cur == RT_CUR_HIT) {
                 sink(q, tag, cur == RT_CUR_HIT);

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -195,6 +196,38 @@ __global__ __launch_bounds__(RT_TRAV_BLOCK) void k_any(SceneView sc, const float
     const int top_bytes = stage_tree_top(sc, s_top);
     occlusion_queue(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
                     [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
+}
+
+// ---- the occlusion kernels over quad records (rt_device.h, "four-wide occlusion walk"): launched instead of k_shadow /
+// k_any when the scene has them
+RT_DEV int stage_quad_top(const SceneView& sc, float4* s_top) {
+    const int n_top = sc.n_quads < RT_QTOP ? sc.n_quads : RT_QTOP;
+    for (int i = threadIdx.x; i < 4 * n_top; i += RT_TRAV_BLOCK) {
+        const int rec = i >> 2, part = i & 3;
+        const float4 v = sc.onodes[i];
+        if (part < 3) s_top[part * RT_QTOP + rec] = v;
+        else ((float2*)(s_top + 3 * RT_QTOP))[rec] = make_float2(v.x, v.y);
+    }
+    __syncthreads();
+    return n_top * RT_ONODE_BYTES;
+}
+__global__ __launch_bounds__(RT_TRAV_BLOCK, 8) void k_shadow4(SceneView sc, const float4* __restrict__ s_o, const float4* __restrict__ s_d,
+                                                      const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors,
+                                                      uint32_t n_shards, uint32_t shard_cap, uint8_t* __restrict__ vis) {
+    __shared__ int stack[RT_QSHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[RT_QTOP_LDS_BYTES / 16];
+    const int top_bytes = stage_quad_top(sc, s_top);
+    occlusion_queue4(sc, s_o, s_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+                     [&](uint32_t q, uint32_t, bool occluded) { vis[q] = occluded ? 0 : 1; });
+}
+__global__ __launch_bounds__(RT_TRAV_BLOCK, 8) void k_any4(SceneView sc, const float4* __restrict__ q_o, const float4* __restrict__ q_d,
+                                                   const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards,
+                                                   uint32_t shard_cap, uint8_t* __restrict__ occ) {
+    __shared__ int stack[RT_QSHORT_STACK * RT_TRAV_BLOCK];
+    __shared__ float4 s_top[RT_QTOP_LDS_BYTES / 16];
+    const int top_bytes = stage_quad_top(sc, s_top);
+    occlusion_queue4(sc, q_o, q_d, counts, cursors, n_shards, shard_cap, (lds_int*)stack + threadIdx.x, (lds_cf4*)s_top, top_bytes,
+                     [&](uint32_t q, uint32_t, bool occluded) { occ[q] = occluded ? 1 : 0; });
 }
 
 // ---- two-level scenes (rt_scene_create_instanced): the same persistent waves over the same sharded queues
@@ -844,6 +877,179 @@ static int pair_tree_depth(const rt_bvh_pair* pairs, int64_t n_pairs, int32_t ro
     return depth;
 }
 
+// The compressed four-wide collapse of the tree of pair records under `root` (rt_device.h, "four-wide occlusion walk").
+// Quad records are appended to `out` (16 words each) in breadth-first order, so the top of the tree leads the array; the
+// exact box of every leaf goes to leaf_box[6 * first slot].  Leaf refs are written as ~slot and resolved by the caller
+// once the number of quad records is known.  Returns the byte offset of the root record, and false in *ok when the tree
+// must stay on the pair walk:
+//   * a box that does not lie inside its parent's box, or is not finite (the argument that the quad walk reaches the same
+//     leaves needs nested boxes; BVH::build makes them so, a caller's own records need not),
+//   * a worst-case stack beyond RT_QSTACK_TOTAL entries, or records beyond 2 GiB.
+struct QuadChild {
+    float mn[3], mx[3];
+    int32_t ref; // pair-record encoding
+};
+// plane q of a quad's grid as the device decodes it (rt_device.h, quad_axis): ONE rounding
+static inline float quad_plane(int q, float step, float org) { return std::fmaf((float)q, step, org); }
+static int32_t build_quads(const rt_bvh_pair* pairs, int32_t root, std::vector<uint32_t>& out, std::vector<float>& leaf_box, bool* ok, int* stack_need) {
+    *ok = true;
+    *stack_need = 0;
+    auto finite3 = [](const float* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); };
+    auto inside = [&](const QuadChild& c, const QuadChild& parent) {
+        for (int a = 0; a < 3; a++)
+            if (!(c.mn[a] >= parent.mn[a] && c.mx[a] <= parent.mx[a])) return false;
+        return true;
+    };
+    auto children_of = [&](int32_t pr, QuadChild* l, QuadChild* r) {
+        const rt_bvh_pair& p = pairs[pr];
+        std::memcpy(l->mn, p.lmin, 12);
+        std::memcpy(l->mx, p.lmax, 12);
+        std::memcpy(r->mn, p.rmin, 12);
+        std::memcpy(r->mx, p.rmax, 12);
+        l->ref = p.lref;
+        r->ref = p.rref;
+        auto ordered = [](const QuadChild& c) { return c.mn[0] <= c.mx[0] && c.mn[1] <= c.mx[1] && c.mn[2] <= c.mx[2]; };
+        return finite3(l->mn) && finite3(l->mx) && finite3(r->mn) && finite3(r->mx) && ordered(*l) && ordered(*r);
+    };
+    auto area = [](const QuadChild& c) {
+        const double x = (double)c.mx[0] - c.mn[0], y = (double)c.mx[1] - c.mn[1], z = (double)c.mx[2] - c.mn[2];
+        return x * y + y * z + z * x;
+    };
+    const size_t first = out.size() / 16;
+    std::vector<int32_t> todo{root};      // pair record each quad starts from; quad k of this tree = todo[k]
+    std::vector<uint8_t> n_children;      // per quad
+    std::vector<int32_t> child_quads;     // per quad, 4 entries: index (within this tree) of the child quad, or -1
+    for (size_t k = 0; k < todo.size(); k++) {
+        if ((first + todo.size() + 4) * RT_ONODE_BYTES > (size_t)0x7fffffff) {
+            *ok = false;
+            return 0;
+        }
+        QuadChild c[4];
+        int n = 2;
+        if (!children_of(todo[k], &c[0], &c[1])) *ok = false;
+        while (*ok && n < 4) { // open the inner child with the largest surface
+            int pick = -1;
+            for (int i = 0; i < n; i++)
+                if (c[i].ref >= 0 && (pick < 0 || area(c[i]) > area(c[pick]))) pick = i;
+            if (pick < 0) break;
+            QuadChild l, r;
+            if (!children_of(c[pick].ref, &l, &r) || !inside(l, c[pick]) || !inside(r, c[pick])) *ok = false;
+            c[pick] = l;
+            c[n++] = r;
+        }
+        if (!*ok) return 0;
+        uint32_t rec[16] = {};
+        // the record's grid: origin = the children's common min (an exact fp32 value: plane 0 decodes to it), step = a power
+        // of two with plane 255 on or beyond the common max AS DECODED
+        uint32_t lo[3][4] = {}, hi[3][4] = {};
+        for (int a = 0; a < 3; a++) {
+            float org = c[0].mn[a], top = c[0].mx[a];
+            for (int i = 1; i < n; i++) {
+                org = std::min(org, c[i].mn[a]);
+                top = std::max(top, c[i].mx[a]);
+            }
+            int e = -126;
+            const double ext = (double)top - (double)org;
+            if (ext > 0) e = std::max(-126, (int)std::ceil(std::log2(ext / 255.0)));
+            for (;; e++) {
+                if (e > 127) { // (extents near FLT_MAX: no grid step holds them)
+                    *ok = false;
+                    return 0;
+                }
+                const float step = std::ldexp(1.0f, e);
+                if (!(quad_plane(255, step, org) >= top)) continue;
+                bool fits = true;
+                for (int i = 0; i < n && fits; i++) {
+                    // largest q with plane(q) <= min; smallest q with plane(q) >= max (plane() is non-decreasing in q)
+                    int ql = (int)std::floor(((double)c[i].mn[a] - (double)org) / (double)step);
+                    ql = std::max(0, std::min(255, ql));
+                    while (ql > 0 && !(quad_plane(ql, step, org) <= c[i].mn[a])) ql--;
+                    while (ql < 255 && quad_plane(ql + 1, step, org) <= c[i].mn[a]) ql++;
+                    int qh = (int)std::ceil(((double)c[i].mx[a] - (double)org) / (double)step);
+                    qh = std::max(0, std::min(255, qh));
+                    while (qh < 255 && !(quad_plane(qh, step, org) >= c[i].mx[a])) qh++;
+                    while (qh > 0 && quad_plane(qh - 1, step, org) >= c[i].mx[a]) qh--;
+                    if (!(quad_plane(ql, step, org) <= c[i].mn[a]) || !(quad_plane(qh, step, org) >= c[i].mx[a])) fits = false;
+                    lo[a][i] = (uint32_t)ql;
+                    hi[a][i] = (uint32_t)qh;
+                }
+                if (fits) break;
+            }
+            std::memcpy(&rec[a], &org, 4);
+            rec[3] |= (uint32_t)(e + 127) << (8 * a);
+            for (int i = 0; i < n; i++) {
+                rec[4 + a] |= lo[a][i] << (8 * i);
+                rec[7 + a] |= hi[a][i] << (8 * i);
+            }
+        }
+        for (int i = 0; i < 4; i++) {
+            int32_t ref;
+            if (i >= n) {
+                ref = RT_REF_NONE;
+                child_quads.push_back(-1);
+            } else if (c[i].ref >= 0) {
+                child_quads.push_back((int32_t)todo.size());
+                ref = (int32_t)((first + todo.size()) * RT_ONODE_BYTES);
+                todo.push_back(c[i].ref);
+            } else {
+                child_quads.push_back(-1);
+                ref = c[i].ref; // ~slot: the caller turns it into the leaf record's ref
+                float* lb = &leaf_box[(size_t)6 * (size_t)(~c[i].ref)];
+                std::memcpy(lb, c[i].mn, 12);
+                std::memcpy(lb + 3, c[i].mx, 12);
+            }
+            std::memcpy(&rec[10 + i], &ref, 4);
+        }
+        out.insert(out.end(), rec, rec + 16);
+        n_children.push_back((uint8_t)n);
+    }
+    // worst-case stack: while a walk is below child i of a quad, up to (children - 1) siblings wait on the stack.  Children
+    // have larger numbers than their parent (breadth-first), so one backward sweep does it.
+    std::vector<int32_t> need(todo.size(), 0);
+    for (size_t k = todo.size(); k-- > 0;) {
+        int32_t deepest = 0;
+        for (int i = 0; i < 4; i++)
+            if (child_quads[4 * k + i] >= 0) deepest = std::max(deepest, need[(size_t)child_quads[4 * k + i]]);
+        need[k] = (int32_t)n_children[k] - 1 + deepest;
+    }
+    *stack_need = need[0];
+    if (need[0] > RT_QSTACK_TOTAL) *ok = false;
+    return (int32_t)(first * RT_ONODE_BYTES);
+}
+
+// The whole onode buffer of a flat scene: quad records, then one leaf record per triangle slot.
+static bool build_onodes(const rt_scene_desc* d, std::vector<uint32_t>& out, int32_t* qroot, int32_t* n_quads, int32_t* leaf_base, int* stack_need) {
+    *stack_need = 0;
+    if (d->root_ref < 0 || d->n_pairs <= 0) return false; // a one-leaf tree has nothing to collapse
+    std::vector<float> leaf_box((size_t)6 * (size_t)d->n_tris, 0.f);
+    bool ok = false;
+    *qroot = build_quads(d->pairs, d->root_ref, out, leaf_box, &ok, stack_need);
+    if (!ok) return false;
+    const size_t nq = out.size() / 16;
+    if ((nq + (size_t)d->n_tris + 1) * RT_ONODE_BYTES > (size_t)0x7fffffff) return false; // refs are 31-bit byte offsets
+    *n_quads = (int32_t)nq;
+    *leaf_base = (int32_t)(nq * RT_ONODE_BYTES);
+    for (size_t k = 0; k < nq; k++)
+        for (int i = 0; i < 4; i++) {
+            int32_t ref;
+            std::memcpy(&ref, &out[16 * k + 10 + i], 4);
+            if (ref < 0 && ref != RT_REF_NONE) {
+                ref = (int32_t)(*leaf_base + (int64_t)(~ref) * RT_ONODE_BYTES) | RT_REF_LEAF;
+                std::memcpy(&out[16 * k + 10 + i], &ref, 4);
+            }
+        }
+    out.resize((nq + (size_t)d->n_tris) * 16);
+    for (int64_t t = 0; t < d->n_tris; t++) {
+        uint32_t* rec = &out[(nq + (size_t)t) * 16];
+        std::memcpy(rec, &leaf_box[(size_t)6 * (size_t)t], 24);
+        std::memcpy(rec + 6, d->tris[t].v0, 12);
+        std::memcpy(rec + 9, d->tris[t].e1, 12);
+        std::memcpy(rec + 12, d->tris[t].e2, 12);
+        rec[15] = (d->tris[t].tri_id & RT_TRI_LEAF_END) ? 1u : 0u;
+    }
+    return true;
+}
+
 // tl == nullptr: the flat scene of rt_scene_create; otherwise the two-level scene of rt_scene_create_instanced
 static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int device, rt_scene** out) {
     if (!d || !out) return fail(RT_ERR_INVALID, "rt_scene_create: null argument");
@@ -1080,6 +1286,27 @@ static int scene_create(const rt_scene_desc* d, const rt_tlas_desc* tl, int devi
         std::sort(s->keys.begin(), s->keys.end(), [&](int a, int b) { return per_type[a] > per_type[b]; });
         s->keys.push_back(RT_KEY_MISS);
     }
+    // The occlusion walks' compressed four-wide records of the same tree: built on request only (RT_TUNE_QUADS=1).  Same flags
+    // bit for bit (tests/test_gpu_quads.py), 0.46 x the visits and 0.64 x the LDS instructions of the pair walk per ray — and
+    // 1.55 x its vector instructions, which is what the walks turn out to be short of: k_shadow 37.6 -> 41.8 ms per step on
+    // cornellbox, 27.1 -> 26.1 ms on the 9.6 M-triangle sphere field (profiles/r03_quad_walk.txt).
+    if (!tl && getenv("RT_TUNE_QUADS")) {
+        std::vector<uint32_t> onodes;
+        int32_t qroot = 0, n_quads = 0, leaf_base = 0;
+        int need = 0;
+        const bool ok = build_onodes(d, onodes, &qroot, &n_quads, &leaf_base, &need);
+        if (ok) {
+            const uint32_t* dq = nullptr;
+            if ((rc = upload(s, onodes.data(), onodes.size(), &dq))) return bail(rc);
+            s->view.onodes = (const float4*)dq;
+            s->view.qroot = qroot;
+            s->view.n_quads = n_quads;
+            s->view.leaf_base = leaf_base;
+        }
+        if (getenv("RT_TUNE_VERBOSE"))
+            std::fprintf(stderr, "rt_scene_create: %lld pair records -> %d quad records (%s), worst-case stack %d\n", (long long)d->n_pairs, n_quads,
+                         ok ? "used by the occlusion walks" : "NOT used: one leaf, boxes that do not nest, or a tree too deep / too large", need);
+    }
     s->view.pairs = (const float4*)pairs;
     s->view.tris = (const float4*)tris;
     s->view.normals = (const float4*)normals;
@@ -1141,6 +1368,8 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
+
+int64_t rt_scene_quad_records(const rt_scene* s) { return s && s->view.onodes ? s->view.n_quads : 0; }
 
 int rt_scene_sync(rt_scene* s) {
     if (!s) return fail(RT_ERR_INVALID, "rt_scene_sync: null scene");
@@ -1230,6 +1459,9 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
         if (two_level)
             hipLaunchKernelGGL(k_shadow2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ, 1);
+        else if (s->view.onodes)
+            hipLaunchKernelGGL(k_any4, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
+                               (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ);
         else
             hipLaunchKernelGGL(k_any, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ);
@@ -1472,6 +1704,9 @@ static int render_common(rt_scene* s, const rt_camera* cam, const rt_options* o,
             if (K > 0 && two_level)
                 hipLaunchKernelGGL(k_shadow2, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
                                    shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis, 0);
+            else if (K > 0 && s->view.onodes)
+                hipLaunchKernelGGL(k_shadow4, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
+                                   shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);
             else if (K > 0)
                 hipLaunchKernelGGL(k_shadow, dim3(pgrid), dim3(RT_TRAV_BLOCK), 0, st, s->view, wave.s_o, wave.s_d, shadow_counts,
                                    shadow_counts + (size_t)RT_COUNTS * RT_CSTRIDE, (uint32_t)RT_SHARDS, (uint32_t)K * pp.shard_cap, wave.vis);

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_c_abi_exports_every_declared_symbol(rta):
     header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
-    declared = sorted(set(re.findall(r"^\s*(?:const\s+char\s*\*|int|void)\s+(rt_[a-z_]+)\s*\(", header, re.M)))
+    declared = sorted(set(re.findall(r"^\s*(?:const\s+char\s*\*|int64_t|int|void)\s+(rt_[a-z_]+)\s*\(", header, re.M)))
     assert declared == sorted(rta.HIP_SYMBOLS)
     lib = ctypes.CDLL(os.path.join(ROOT, "raytracing_amd", "librt_hip.so"))
     for name in declared:
