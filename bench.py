@@ -6,7 +6,8 @@ file's Camera node chain, uniform 16x8 environment.  One "step" = SPP_STEP (32) 
 one rt_render call (cut by the library into four 8-spp wavefront passes in flight); the default 32 steps are the
 configuration's 1024 spp.
 
-Multi-GPU (one process per GPU, torch.distributed for the launch, the barriers and the statistics):
+Multi-GPU (one process per GPU; torch.distributed over gloo for the launch, the barriers and the statistics, RCCL only for the
+frame's reduce, through the library's own communicator):
   --scaling strong (default)  the frame is FIXED: steps x SPP_STEP samples per pixel of ONE Hammersley set.  With
                               --sharding samples each rank renders its contiguous window of the set, with --sharding tiles
                               its interleaved 64x64 tiles (rt_render_tiles) at all samples.  T_1 / (G T_G) is the north
@@ -15,7 +16,8 @@ Multi-GPU (one process per GPU, torch.distributed for the launch, the barriers a
 Either way the ranks share nothing while rendering (no data-path collective) and ONE reduce of the fp32 radiance buffer
 to rank 0 — rt_reduce of the C-ABI: RCCL over xGMI — closes the frame inside the timed region.
 
-Prints ONE JSON line on rank 0.  `value` = (closest-hit + shadow rays actually traced, all ranks) / wall seconds, rays
+The default one-GPU run appends a short leg on the HBM-bound workload (`"side": {"spheres10m": ...}`, --no-side skips it) and the
+CPU baseline.  Prints ONE JSON line on rank 0.  `value` = (closest-hit + shadow rays actually traced, all ranks) / wall seconds, rays
 counted by device counters, radiance accumulated in HBM (device output, nothing crosses PCIe in the timed region)."""
 import argparse
 import hashlib
@@ -31,7 +33,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 WIDTH, HEIGHT, DEPTH, SPP_STEP = 1920, 1080, 8, 32  # (main() raises the raster for --workload spheres10m)
 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; L2 (4 MiB per XCD, 32 MiB aggregate) ~34.5 TB/s; LDS ~150 TB/s for ds_read_b64/b128 with every CU streaming
 HBM_PEAK_GBPS, L2_PEAK_GBPS, LDS_PEAK_GBPS = 8000.0, 34500.0, 150000.0
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def kernel_source_sha16():
@@ -156,6 +158,85 @@ def roofline(args, stats, alone, visits, two_level):
     return out
 
 
+def make_scene(rta, scenes, np, workload, max_per_leaf):
+    """-> (scene, camera factory(width, height), label, depth, visits file stem, two_level, width, height)"""
+    width, height, depth, two_level = 1920, 1080, DEPTH, False
+    visits_name = "visits_cornellbox_1080p_d8"
+    if workload == "cornellbox":
+        sc = scenes.cornellbox(rta)
+        cam_of = lambda w, h: scenes.cornell_camera(rta, sc, w, h)
+        label = "cornellbox.glb"
+    elif workload == "random1m":  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
+        sc = scenes.random_triangles(rta, 1_000_000)
+        cam_of = lambda w, h: scenes.random_triangles_camera(rta, w, h)
+        depth = 1
+        visits_name = "visits_random1m_1080p_d1"
+        label = "1M random triangles (seed 1234), one rectangle light"
+    elif workload == "instanced5m":  # BASELINE configs[4], kept two-level (SURVEY 8 f-2): TLAS + ONE mesh BVH + per-instance ray transforms
+        sc = scenes.legacy_instanced(rta, max_per_leaf=max_per_leaf)  # TriangleMesh(mesh, max_per_node); the reference's constant is 1
+        cam_of = lambda w, h: scenes.legacy_instanced_camera(rta, w, h)
+        visits_name = "visits_instanced5m_1080p_d8"
+        two_level = True
+        label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), rectangle light + uniform environment"
+    elif workload == "instanced5m_flat":  # the same surfaces flattened into one 5 M-triangle world-space mesh (Scene::add_instance)
+        sc = scenes.legacy_instanced_flat(rta)
+        cam_of = lambda w, h: scenes.legacy_instanced_camera(rta, w, h)
+        visits_name = "visits_instanced5m_flat_1080p_d8"
+        label = "room + one 99 856-triangle mesh x 50, FLATTENED into one 5 M-triangle mesh, rectangle light + uniform environment"
+    else:  # BASELINE configs[3] geometry, one GPU's share: 614 MB of pair records + 922 MB of triangles and normals, beyond every cache
+        width, height = 3840, 2160
+        sc = scenes.sphere_field(rta)
+        sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
+        cam_of = lambda w, h: scenes.random_triangles_camera(rta, w, h)
+        visits_name = "visits_spheres10m_4k_d8"
+        label = "10 000 tessellated spheres (9.6M triangles, seed 1234), rectangle light + uniform environment"
+    return sc, cam_of, label, depth, visits_name, two_level, width, height
+
+
+def side_leg(rta, scenes, np, torch, workload, device, steps=4, spp_step=8):
+    """A short leg on the ONE workload whose roof is HBM (BASELINE configs[3] geometry, 9.6 M triangles at 4K: the records do not
+    fit any cache), so that a driver-run line carries a number for it: whole-step throughput with passes in flight, and the
+    dominant kernel against the HBM peak exactly as roofline() prices the headline's.  BVH build time is reported, not timed in."""
+    import types
+
+    t0 = time.time()
+    sc, cam_of, label, depth, visits_name, two_level, width, height = make_scene(rta, scenes, np, workload, 2)
+    sc.build(max_per_leaf=2)
+    t_build = time.time() - t0
+    sc.upload(device)
+    cam = cam_of(width, height)
+    frame = torch.zeros((height, width, 3), dtype=torch.float32, device=f"cuda:{device}")
+    torch.cuda.synchronize()
+
+    def render(i, **kw):
+        _, st = sc.render(cam, width, height, spp=spp_step, max_depth=depth, seed=1, spp_begin=i * spp_step, spp_total=(steps + 2) * spp_step,
+                          device_out=frame.data_ptr(), **kw)
+        return st
+
+    for i in range(2):
+        render(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats = None
+    for i in range(steps):
+        st = render(2 + i, timing=True)
+        stats = dict(st) if stats is None else {k: stats[k] + st[k] for k in st}
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rays = stats["rays_closest"] + stats["rays_shadow"]
+    out = {"workload": f"{label}, BVH::build(bounds, 2, BVH_SAH), {width}x{height}, {depth} bounces, {spp_step} spp per step", "value": rays / elapsed / 1e6,
+           "unit": "Mrays/s", "samples_per_s": stats["paths"] / elapsed, "steps": steps, "warmup": 2, "ms_per_step": elapsed * 1000.0 / steps,
+           "triangles": int(len(sc.array(rta.ARR_TRIS))), "bvh_build_s": t_build, "rays_per_sample": rays / stats["paths"]}
+    visits_json = os.path.join(ROOT, "profiles", visits_name + "_leaf2.json")
+    if os.path.exists(visits_json):
+        render(0, timing=True, serial=True)
+        alone = render(1, timing=True, serial=True)
+        out["roofline"] = roofline(types.SimpleNamespace(workload=workload, max_per_leaf=2), stats, alone, json.load(open(visits_json)), two_level)
+        out["kernel_ms_standalone_step"] = {k: alone[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
+    del sc, frame
+    return out
+
+
 def main():
     global WIDTH, HEIGHT
     ap = argparse.ArgumentParser()
@@ -165,6 +246,7 @@ def main():
     ap.add_argument("--spp-per-pass", type=int, default=0)
     ap.add_argument("--spp-step", type=int, default=SPP_STEP, help="samples per pixel of one step (one rt_render call over the whole frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the spheres10m side leg of the default one-GPU run")
     ap.add_argument("--max-per-leaf", type=int, default=None, help="max_per_node of BVH::build (1 = what the reference's TriangleMesh passes); "
                     "default: 2, random1m 1 (instanced5m: TriangleMesh(mesh, max_per_node))")
     ap.add_argument("--workload", choices=["cornellbox", "random1m", "spheres10m", "instanced5m", "instanced5m_flat"], default="cornellbox",
@@ -201,11 +283,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        # Launch, barriers and statistics go over gloo (CPU tensors); RCCL is used for exactly one thing, the frame's reduce, through
+        # the library's own communicator (rt_comm_create).  Torch's NCCL process group is NOT created beside it: two RCCL
+        # communicators over the same GPUs in one process is a combination no hardware run has vouched for, and the
+        # control traffic is a few bytes.  RT_BENCH_TORCH_RCCL=1 brings torch's group back (the frame then goes through dist.reduce).
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearse:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch_rccl = None
+    if world > 1 and not rehearse and os.environ.get("RT_BENCH_TORCH_RCCL"):
+        torch_rccl = dist.new_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     if args.max_per_leaf is None:  # measured per workload: random1m walks 3 % slower with two triangles per leaf, the others 5-8 % faster
         args.max_per_leaf = 1 if args.workload == "random1m" else 2
@@ -216,37 +302,8 @@ def main():
 
     # ---- scene: load, build the BVH on the host ONCE (rank 0; the other ranks take its nodes), flatten, upload
     t0 = time.time()
-    depth = DEPTH
-    two_level = False
-    visits_name = "visits_cornellbox_1080p_d8"
-    if args.workload == "cornellbox":
-        sc = scenes.cornellbox(rta)
-        cam_of = lambda: scenes.cornell_camera(rta, sc, WIDTH, HEIGHT)
-        label = "cornellbox.glb"
-    elif args.workload == "random1m":  # BASELINE configs[2]: traversal-bound, incoherent; the tree (64 MB) and triangles (48 MB) exceed the L2
-        sc = scenes.random_triangles(rta, 1_000_000)
-        cam_of = lambda: scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
-        depth = 1
-        visits_name = "visits_random1m_1080p_d1"
-        label = "1M random triangles (seed 1234), one rectangle light"
-    elif args.workload == "instanced5m":  # BASELINE configs[4], kept two-level: TLAS + ONE mesh BVH + per-instance ray transforms
-        sc = scenes.legacy_instanced(rta, max_per_leaf=args.max_per_leaf)  # TriangleMesh(mesh, max_per_node); the reference's constant is 1
-        cam_of = lambda: scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
-        visits_name = "visits_instanced5m_1080p_d8"
-        two_level = True
-        label = "room of Rectangle instances + one 99 856-triangle mesh x 50 Instance transforms (two-level), rectangle light + uniform environment"
-    elif args.workload == "instanced5m_flat":  # the same surfaces flattened into one 5 M-triangle world-space mesh (Scene::add_instance)
-        sc = scenes.legacy_instanced_flat(rta)
-        cam_of = lambda: scenes.legacy_instanced_camera(rta, WIDTH, HEIGHT)
-        visits_name = "visits_instanced5m_flat_1080p_d8"
-        label = "room + one 99 856-triangle mesh x 50, FLATTENED into one 5 M-triangle mesh, rectangle light + uniform environment"
-    else:  # BASELINE configs[3] geometry, one GPU's share: 614 MB of pair records + 922 MB of triangles and normals, beyond every cache
-        WIDTH, HEIGHT = 3840, 2160
-        sc = scenes.sphere_field(rta)
-        sc.set_env(np.full((8, 16, 3), 0.3, np.float32))
-        cam_of = lambda: scenes.random_triangles_camera(rta, WIDTH, HEIGHT)
-        visits_name = "visits_spheres10m_4k_d8"
-        label = "10 000 tessellated spheres (9.6M triangles, seed 1234), rectangle light + uniform environment"
+    sc, cam_of_wh, label, depth, visits_name, two_level, WIDTH, HEIGHT = make_scene(rta, scenes, np, args.workload, args.max_per_leaf)
+    cam_of = lambda: cam_of_wh(WIDTH, HEIGHT)
     bvh_shared = False
     if two_level:
         sc.build()  # (the mesh BVH was built by new_triangle_mesh: 0.2 s)
@@ -288,7 +345,11 @@ def main():
     else:
         first, count, spp_total = 0, K * spp_step, K * spp_step
         tiles = rta.shard_tiles(rank, world, WIDTH, HEIGHT, args.tile) if world > 1 else None
-    calls = [(first + b, min(spp_step, count - b)) for b in range(0, count, spp_step)]  # this rank's rt_render calls of the timed region
+    # this rank's rt_render calls of the timed region: as few as spp_step allows, of EQUAL size (80 spp are 27 + 27 + 26, not
+    # 32 + 32 + 16: a short last call would run 4-spp passes, which the walks do measurably worse)
+    n_calls = (count + spp_step - 1) // spp_step
+    sizes = [count // n_calls + (1 if i < count % n_calls else 0) for i in range(n_calls)]
+    calls = [(first + sum(sizes[:i]), sizes[i]) for i in range(n_calls)]
     frame = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=f"cuda:{local_rank}")
     scratch = torch.zeros_like(frame)
     torch.cuda.synchronize()  # the library works on its own streams: the fills must have finished (include/rt_hip.h, RT_RENDER_DEVICE_OUT)
@@ -301,21 +362,23 @@ def main():
     # the frame's reduce: rt_reduce (RCCL through the C-ABI); the one-GPU rehearsal goes through a host copy and gloo
     comm = None
     reduce_path = "none (one GPU)"
-    if world > 1 and not rehearse:
-        uid = torch.from_numpy(rta.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(f"cuda:{local_rank}")
+    if world > 1 and not rehearse and torch_rccl is None:
+        uid = torch.from_numpy(rta.Comm.unique_id() if rank == 0 else np.zeros(128, np.uint8))
         dist.broadcast(uid, src=0)
         try:
-            comm = rta.Comm.create(uid.cpu().numpy(), rank, world, local_rank)
+            comm = rta.Comm.create(uid.numpy(), rank, world, local_rank)
             reduce_path = "rt_reduce (C-ABI, RCCL ncclReduce over xGMI)"
-        except rta.RtError as e:  # loud, and the run still measures: the same collective through torch's RCCL
-            print(f"bench.py: rank {rank}: rt_comm_create failed ({e}); the frame reduce falls back to torch.distributed", file=sys.stderr, flush=True)
-            reduce_path = "torch.distributed.reduce (RCCL) — rt_comm_create failed, see stderr"
-        ok = torch.tensor([1 if comm is not None else 0], device=f"cuda:{local_rank}")
+        except rta.RtError as e:  # loud, and the run still measures: the same sum through a host copy
+            print(f"bench.py: rank {rank}: rt_comm_create failed ({e}); the frame reduce falls back to gloo through a host copy", file=sys.stderr, flush=True)
+            reduce_path = "gloo through a host copy — rt_comm_create failed, see stderr"
+        ok = torch.tensor([1 if comm is not None else 0])
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0 and comm is not None:  # all ranks must take the same path
             comm.close()
             comm = None
-            reduce_path = "torch.distributed.reduce (RCCL) — rt_comm_create failed on another rank"
+            reduce_path = "gloo through a host copy — rt_comm_create failed on another rank"
+    elif world > 1 and torch_rccl is not None:
+        reduce_path = "torch.distributed.reduce over torch's own RCCL group (RT_BENCH_TORCH_RCCL)"
     elif world > 1:
         reduce_path = "gloo through a host copy (RT_BENCH_REHEARSE)"
 
@@ -324,15 +387,15 @@ def main():
             return
         if comm is not None:
             comm.reduce(buf.data_ptr(), buf.numel(), 0)
-        elif rehearse:
+        elif torch_rccl is not None:
+            dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, group=torch_rccl)
+        else:
             host = buf.cpu()
             sharding.reduce_frame(host, dst=0)
             buf.copy_(host)
-        else:
-            sharding.reduce_frame(buf, dst=0)
 
     for i in range(W):  # warm-up: W full-size calls + the collective's first use (channel set-up is not the frame's cost)
-        render(first, min(spp_step, count), False, target=scratch)
+        render(first, calls[0][1], False, target=scratch)
     if W > 0 or world > 1:
         reduce_frame(scratch)
     torch.cuda.synchronize()
@@ -344,6 +407,8 @@ def main():
     for begin, n in calls:
         st = render(begin, n, True)
         stats = dict(st) if stats is None else {k: stats[k] + st[k] for k in st}
+    torch.cuda.synchronize()
+    t_rendered = time.perf_counter() - t0  # this rank's own rendering: what a load imbalance shows up in
     reduce_frame(frame)  # the frame's single reduce (no-op at world 1)
     torch.cuda.synchronize()
     if world > 1:
@@ -351,14 +416,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    totals = torch.tensor([elapsed, float(stats["rays_closest"]), float(stats["rays_shadow"]), float(stats["paths"])],
-                          dtype=torch.float64, device="cpu" if rehearse else f"cuda:{local_rank}")
+    mine = torch.tensor([elapsed, float(stats["rays_closest"]), float(stats["rays_shadow"]), float(stats["paths"]), t_rendered, float(count),
+                         float(len(calls))], dtype=torch.float64)
+    per_rank = [mine]
     if world > 1:
-        tmax = totals[:1].clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-        totals[0] = tmax[0]
-    elapsed, rays_c, rays_s, paths = [float(x) for x in totals.tolist()]
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    table = torch.stack(per_rank)  # [rank, field]
+    elapsed = float(table[:, 0].max())  # the job takes as long as its slowest rank
+    rays_c, rays_s, paths = float(table[:, 1].sum()), float(table[:, 2].sum()), float(table[:, 3].sum())
 
     if rank == 0:
         rays = rays_c + rays_s
@@ -387,6 +453,9 @@ def main():
                 "sharding": args.sharding if world > 1 else None,
                 "reduce": reduce_path,
                 "bvh_built_once_and_shared": bvh_shared,
+                "control_plane": "gloo (launch, barriers, statistics)" if world > 1 else None,
+                "calls_per_rank": [int(x) for x in table[:, 6].tolist()],
+                "spp_per_rank": [int(x) for x in table[:, 5].tolist()],
                 "rays_closest": rays_c,
                 "rays_shadow": rays_s,
                 "rays_per_sample": rays / paths,
@@ -394,6 +463,13 @@ def main():
                 "frame_mean": float(frame.mean().item()) / total_spp,
             },
         }
+        # per-rank view of the timed region, so that an imbalance is visible in the line: a rank's own rendering time (before the
+        # reduce), its wall time through the closing barrier, and the rays it traced
+        render_s = table[:, 4].tolist()
+        out["per_rank"] = {"render_s": render_s, "elapsed_s": table[:, 0].tolist(), "rays": (table[:, 1] + table[:, 2]).tolist(),
+                           "render_s_min": min(render_s), "render_s_max": max(render_s),
+                           "imbalance": max(render_s) / (sum(render_s) / len(render_s)) - 1.0,
+                           "reduce_and_barrier_s_on_slowest": elapsed - max(render_s)}
         # ---- roofline of the dominant kernel: one untimed extra step with one pass at a time, so that a launch's duration is its own
         visits = json.load(open(visits_json)) if visits_json and os.path.exists(visits_json) else None
         if visits:
@@ -404,6 +480,11 @@ def main():
         out["kernel_ms"] = {k: stats[k] for k in ("ms_total", "ms_generate", "ms_closest", "ms_shade", "ms_shadow", "ms_accumulate")}
         if not args.no_cpu_baseline and world == 1 and args.workload == "cornellbox":
             out["cpu_baseline"] = cpu_baseline(scenes, rta, sc)
+        if not args.no_side and world == 1 and args.workload == "cornellbox":
+            try:
+                out["side"] = {"spheres10m": side_leg(rta, scenes, np, torch, "spheres10m", local_rank)}
+            except Exception as e:  # the headline line must not depend on the side leg
+                out["side"] = {"spheres10m": {"error": repr(e)}}
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -43,7 +43,7 @@ def _check_common(j, n_gpus, steps, warmup):
 
 
 def test_bench_line(gpu):
-    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-side"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     j = _last_json(p.stdout)
@@ -53,10 +53,26 @@ def test_bench_line(gpu):
     assert abs(j["value"] - rays / (j["ms_per_step"] * 2 * 1e-3) / 1e6) < 1e-3 * j["value"]
 
 
+def test_bench_side_leg_on_the_hbm_bound_workload(gpu):
+    """The default one-GPU run carries a short leg on the 9.6 M-triangle field (`side.spheres10m`), priced like the headline."""
+    p = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _last_json(p.stdout)
+    side = j["side"]["spheres10m"]
+    assert "error" not in side, side
+    assert side["value"] > 0 and side["unit"] == "Mrays/s" and side["triangles"] > 9_000_000 and "3840x2160" in side["workload"]
+    r = side["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] in ("k_closest", "k_shadow") and r["algorithmic"]["bytes_per_ray"] > 1000
+    if r["counters"]["matches_loaded_kernels"] and r["traffic"] is not None:
+        assert 0 < r["frac"] <= 1
+    assert j["per_rank"]["imbalance"] == 0.0 and len(j["per_rank"]["render_s"]) == 1
+
+
 def test_bench_two_ranks_share_the_sample_set(gpu):
     env = dict(os.environ, RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-side"]
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert p.returncode == 0, p.stderr[-2000:]
     j = _last_json(p.stdout)
@@ -65,10 +81,27 @@ def test_bench_two_ranks_share_the_sample_set(gpu):
     one = _run_one_gpu(2)
     assert abs(j["config"]["frame_mean"] - one["config"]["frame_mean"]) < 1e-5 * one["config"]["frame_mean"]  # the same frame as one GPU renders
     assert j["config"]["rays_closest"] == one["config"]["rays_closest"] and j["config"]["rays_shadow"] == one["config"]["rays_shadow"]
+    # the line shows every rank: its own rendering time, its rays, and how uneven the ranks were
+    pr = j["per_rank"]
+    assert len(pr["render_s"]) == len(pr["rays"]) == 2 and sum(pr["rays"]) == j["config"]["rays_closest"] + j["config"]["rays_shadow"]
+    assert 0 < pr["render_s_min"] <= pr["render_s_max"] <= max(pr["elapsed_s"]) and pr["imbalance"] >= 0
+    assert j["config"]["control_plane"].startswith("gloo") and j["config"]["spp_per_rank"] == [32, 32]
+
+
+def test_bench_strong_scaling_cuts_a_rank_window_into_equal_calls(gpu):
+    """5 steps of 32 spp over 2 ranks = 80 spp per rank: three calls of 27 + 27 + 26, not 32 + 32 + 16."""
+    env = dict(os.environ, RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-side"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = _last_json(p.stdout)
+    assert j["config"]["spp_per_rank"] == [80, 80] and j["config"]["calls_per_rank"] == [3, 3]
+    assert j["config"]["rays_closest"] > 0 and abs(j["samples_per_s"] * j["ms_per_step"] * 5e-3 - 1920 * 1080 * 160) < 1.0
 
 
 def _run_one_gpu(steps):
-    p = subprocess.run([sys.executable, "bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT,
+    p = subprocess.run([sys.executable, "bench.py", "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-side"], cwd=ROOT,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     return _last_json(p.stdout)
@@ -87,7 +120,7 @@ def _free_port():
 def test_bench_two_ranks_tiles_and_weak(gpu, extra, expect):
     env = dict(os.environ, RT_BENCH_REHEARSE="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-side"] + extra
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
     assert p.returncode == 0, p.stderr[-2000:]
     j = _last_json(p.stdout)

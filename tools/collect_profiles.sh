@@ -9,7 +9,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 RT_PMC_ARGS="--workload $WL" bash tools/profile_pmc.sh "$OUT/pmc" &&
 python3 tools/summarize_pmc.py "$OUT/pmc" "$OUT/pmc_summary_$WL.json" "$WL" "$LEAF" > /dev/null &&
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline > "$OUT/prof.log" 2>&1 &&
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline --no-side > "$OUT/prof.log" 2>&1 &&
 cp "$OUT"/prof/*/*_kernel_stats.csv "$OUT/kernel_stats_${WL}_steps4.csv" &&
 cp "$OUT/pmc_summary_$WL.json" profiles/r02_pmc_summary_$WL.json &&
 timeout -k 10 600 python3 bench.py --workload "$WL" --steps "$STEPS" > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err" &&

@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/sq}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-timeout -s KILL 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq1" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/sq1.log" 2>&1 || { echo "pass failed"; tail -5 "$OUT/sq1.log"; exit 1; }
+timeout -s KILL 240 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq1" -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-side > "$OUT/sq1.log" 2>&1 || { echo "pass failed"; tail -5 "$OUT/sq1.log"; exit 1; }
 python3 tools/summarize_pmc.py "$OUT" "$OUT/summary.json" > /dev/null
 python3 - "$OUT/summary.json" <<'PY'
 import json, sys
