@@ -298,6 +298,15 @@ int rt_trace_any(rt_scene* scene, const rt_ray* rays, const float* tmax, int64_t
  * in the reference (its trace_scene has one walk, Object.h:273-344). */
 int64_t rt_scene_quad_records(const rt_scene* scene);
 
+/* The records behind rt_scene_quad_records, built on the host WITHOUT a GPU (what rt_scene_create builds under RT_TUNE_QUADS=1),
+ * for inspection and for tests: 16 words per record, `*n_quads` quad records followed by one leaf record per triangle slot
+ * (layout: raytracing_amd/csrc/rt_device.h, "four-wide occlusion walk").  out_words may be null to ask for the size: the call
+ * then only sets *n_quads.  Returns RT_ERR_INVALID when the tree cannot be collapsed (one leaf, boxes that do not nest, a
+ * worst-case stack beyond 96 entries: *stack_need says how deep), RT_ERR_LIMIT when capacity_words is too small.  No
+ * counterpart in the reference. */
+int rt_collapse_quads(const rt_bvh_pair* pairs, int64_t n_pairs, int32_t root_ref, const rt_tri* tris, int64_t n_tris,
+                      uint32_t* out_words, int64_t capacity_words, int64_t* n_quads, int32_t* qroot, int32_t* stack_need);
+
 /* rt_trace_closest for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
  * call hipMalloc — tight serving loops, harnesses that forbid allocation, code that sets up HIP graph capture around its OWN
  * streams (the call itself synchronises the scene's stream and asks for pointer attributes: it cannot run INSIDE a capture).  Same walk, same

@@ -85,7 +85,7 @@ HIP_SYMBOLS = ["rt_last_error", "rt_device_count", "rt_scene_create", "rt_scene_
                "rt_trace_closest", "rt_trace_closest_indexed", "rt_trace_any", "rt_trace_closest_noalloc", "rt_render", "rt_render_tiles",
                "rt_resolve", "rt_scene_sync", "rt_comm_unique_id", "rt_comm_create", "rt_comm_create_local", "rt_comm_rank",
                "rt_comm_world", "rt_reduce", "rt_comm_destroy", "rt_buffer_alloc", "rt_buffer_download", "rt_buffer_zero",
-               "rt_buffer_free", "rt_scene_quad_records"]
+               "rt_buffer_free", "rt_scene_quad_records", "rt_collapse_quads"]
 NOALLOC_MAX_RAYS = 1 << 19
 
 
@@ -122,6 +122,7 @@ def load_libraries():
     hip.rt_scene_sync.argtypes = [vp]
     hip.rt_scene_quad_records.argtypes = [vp]
     hip.rt_scene_quad_records.restype = i64
+    hip.rt_collapse_quads.argtypes = [vp, i64, i32, vp, i64, vp, i64, vp, vp, vp]
     host.rth_bvh_build.argtypes = [vp, i32, i32, i32, vp, vp]
     host.rth_bvh_build.restype = i32
     host.rth_scene_new.restype = vp
@@ -260,6 +261,19 @@ def shard_tiles(rank, world, width, height, tile=64):
     if n > 0:
         host.rth_shard_tiles(rank, world, width, height, tile, _ptr(out), n)
     return out
+
+
+def collapse_quads(pairs, root_ref, flat_tris):
+    """rt_collapse_quads: the occlusion walk's compressed four-wide records of a pair tree, built on the host (no GPU).
+    -> (words [n_records, 16] uint32: quad records then one leaf record per triangle slot, n_quads, qroot, worst-case stack)"""
+    hip, _ = load_libraries()
+    pairs = np.ascontiguousarray(pairs, dtype=PAIR)
+    tris = np.ascontiguousarray(flat_tris, dtype=FLAT_TRI)
+    nq, root, need = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+    _check(hip.rt_collapse_quads(_ptr(pairs), len(pairs), int(root_ref), _ptr(tris), len(tris), None, 0, C.byref(nq), C.byref(root), C.byref(need)))
+    out = np.zeros((nq.value + len(tris), 16), np.uint32)
+    _check(hip.rt_collapse_quads(_ptr(pairs), len(pairs), int(root_ref), _ptr(tris), len(tris), _ptr(out), out.size, C.byref(nq), C.byref(root), C.byref(need)))
+    return out, int(nq.value), int(root.value), int(need.value)
 
 
 def bvh_build(bounds6, max_per_node=1, strategy=1):

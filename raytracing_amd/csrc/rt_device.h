@@ -1939,20 +1939,32 @@ RT_DEV void light_sample(const SceneView& sc, const TB& tb, const rt_light& L, R
     float b1 = r.next();
     float b2 = r.next();
     int lo = 0, hi = L.count - 1;
+#ifdef RT_PROBE_NOSEARCH // timing probe: no CDF search (wrong distribution, same memory traffic otherwise)
+    lo = (int)(r0 * (float)L.count);
+    lo = lo > hi ? hi : lo;
+#else
     while (lo < hi) {
         int mid = (lo + hi) / 2;
         if (r0 < tb.em_cdf(L.first + mid)) hi = mid;
         else lo = mid + 1;
     }
+#endif
     const int slot = tb.em_slot(L.first + lo);
     const float4* tp = sc.tris + 3 * (size_t)slot;
     const float4* np = sc.normals + 3 * (size_t)slot;
     float su = sqrtf(b1);
     float u = 1.f - su;
     float v = b2 * su;
+#ifdef RT_PROBE_NOGATHER // timing probe: no triangle / normal fetch for the sampled emitter
+    *point = V3(0.1f * u, 2.f + 0.1f * v, 0.f);
+    *normal = V3(0.f, -1.f, 0.f);
+    (void)tp;
+    (void)np;
+#else
     *point = V3(tp[0]) + u * V3(tp[1]) + v * V3(tp[2]);
     V3 N = (1.f - u - v) * V3(np[0]) + u * V3(np[1]) + v * V3(np[2]);
     *normal = normalize(N);
+#endif
 }
 
 // hammersley_2d + Camera::get_ray + Filter::sample (Utils.h:138-151, Scene.h:61-75, Filter.h)

@@ -1369,6 +1369,38 @@ void rt_scene_destroy(rt_scene* s) {
     delete s;
 }
 
+int rt_collapse_quads(const rt_bvh_pair* pairs, int64_t n_pairs, int32_t root_ref, const rt_tri* tris, int64_t n_tris, uint32_t* out_words,
+                      int64_t capacity_words, int64_t* n_quads, int32_t* qroot, int32_t* stack_need) {
+    if (!pairs || !tris || !n_quads || n_pairs <= 0 || n_tris <= 0) return fail(RT_ERR_INVALID, "rt_collapse_quads: bad argument");
+    if (root_ref >= n_pairs || (root_ref < 0 && ~root_ref >= n_tris)) return fail(RT_ERR_INVALID, "rt_collapse_quads: root_ref out of range");
+    for (int64_t i = 0; i < n_pairs; i++)
+        for (int32_t r : {pairs[i].lref, pairs[i].rref})
+            if (r >= 0 ? r >= n_pairs : ~r >= n_tris) return fail(RT_ERR_INVALID, "rt_collapse_quads: child ref out of range");
+    {
+        std::vector<uint8_t> seen((size_t)n_pairs, 0);
+        const int depth = pair_tree_depth(pairs, n_pairs, root_ref, seen);
+        if (depth < 0 || depth > RT_STACK_TOTAL) return fail(RT_ERR_INVALID, "rt_collapse_quads: the pair records do not form a tree of at most 64 levels");
+    }
+    rt_scene_desc d{};
+    d.root_ref = root_ref;
+    d.n_pairs = n_pairs;
+    d.pairs = pairs;
+    d.n_tris = n_tris;
+    d.tris = tris;
+    std::vector<uint32_t> onodes;
+    int32_t root = 0, nq = 0, leaf_base = 0;
+    int need = 0;
+    const bool ok = build_onodes(&d, onodes, &root, &nq, &leaf_base, &need);
+    if (stack_need) *stack_need = need;
+    if (!ok) return fail(RT_ERR_INVALID, "rt_collapse_quads: this tree stays on the pair walk (one leaf, boxes that do not nest, or too deep / too large)");
+    *n_quads = nq;
+    if (qroot) *qroot = root;
+    if (!out_words) return RT_OK;
+    if ((int64_t)onodes.size() > capacity_words) return fail(RT_ERR_LIMIT, "rt_collapse_quads: out_words is too small");
+    std::memcpy(out_words, onodes.data(), onodes.size() * sizeof(uint32_t));
+    return RT_OK;
+}
+
 int64_t rt_scene_quad_records(const rt_scene* s) { return s && s->view.onodes ? s->view.n_quads : 0; }
 
 int rt_scene_sync(rt_scene* s) {
