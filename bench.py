@@ -133,7 +133,7 @@ def roofline(args, stats, alone, visits, two_level):
     if "valu_busy_frac" in counters:
         # what the counters say binds the kernel when its HBM fraction is small: the share of SIMD cycles that issue vector
         # arithmetic, and how many of a wave's 64 lanes those instructions carry
-        out["limiter"] = {"resource": "vector ALU issue" if counters["valu_busy_frac"] > 0.7 else "dependent latency of a node visit at the SIMD's 8 wave slots (profiles/r02_walk_probes.txt)",
+        out["limiter"] = {"resource": "vector ALU issue" if counters["valu_busy_frac"] > 0.7 else "no single unit: LDS / vector-L1 transactions per visit against vector issue at ~37 of 64 lanes, 8 waves per SIMD (profiles/r02_walk_probes.txt, profiles/r03_quad_walk.txt)",
                           "valu_busy_frac": counters["valu_busy_frac"], "valu_active_lanes_of_64": counters.get("valu_active_lanes_of_64")}
     alg = {"bytes_per_launch": alg_bytes, "bytes_per_ray": v["bytes_per_ray"], "gbps": alg_bytes / launch_s / 1e9,
            "inner_per_ray": v["inner_per_ray"], "triangles_per_ray": v["leaf_per_ray"]}

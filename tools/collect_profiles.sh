@@ -11,6 +11,6 @@ RT_PMC_ARGS="--workload $WL" bash tools/profile_pmc.sh "$OUT/pmc" &&
 python3 tools/summarize_pmc.py "$OUT/pmc" "$OUT/pmc_summary_$WL.json" "$WL" "$LEAF" > /dev/null &&
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof" -- python3 bench.py --workload "$WL" --steps 4 --warmup 1 --no-cpu-baseline --no-side > "$OUT/prof.log" 2>&1 &&
 cp "$OUT"/prof/*/*_kernel_stats.csv "$OUT/kernel_stats_${WL}_steps4.csv" &&
-cp "$OUT/pmc_summary_$WL.json" profiles/r02_pmc_summary_$WL.json &&
+cp "$OUT/pmc_summary_$WL.json" profiles/r03_pmc_summary_$WL.json &&
 timeout -k 10 600 python3 bench.py --workload "$WL" --steps "$STEPS" > "$OUT/bench_$WL.json" 2> "$OUT/bench_$WL.err" &&
 tail -c 600 "$OUT/bench_$WL.json"
