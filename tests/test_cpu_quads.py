@@ -183,3 +183,63 @@ def test_quad_walk_reaches_the_reference_walks_leaves(rta, per_leaf):
         extra += cand - len(got)
         total += len(want)
     assert total > 500 and extra < 0.25 * total  # the conservative boxes let few extra leaves through to their exact test
+
+
+def test_collapse_refuses_what_the_quad_walk_cannot_prove(rta):
+    """A caller's own records need not nest; NaN / infinite boxes, one-leaf trees and bad references are refused too —
+    rt_scene_create then keeps such a scene on the pair walk (and says so under RT_TUNE_VERBOSE)."""
+    sc = scenes.quad_room(rta)
+    sc.build()
+    pairs, tris, root = _flat(rta, sc)
+    words, nq, _, _ = rta.collapse_quads(pairs, root, tris)
+    assert nq > 0
+    inner = [i for i in range(len(pairs)) if pairs[i]["lref"] >= 0][0]  # a record whose left child is a record itself
+    child = int(pairs[inner]["lref"])
+    bad = pairs.copy()
+    bad[child]["lmax"][0] = bad[inner]["lmax"][0] + 1.0  # the grandchild now sticks out of its parent's box
+    with pytest.raises(rta.RtError, match="pair walk"):
+        rta.collapse_quads(bad, root, tris)
+    for poison in (np.nan, np.inf):
+        bad = pairs.copy()
+        bad[child]["rmin"][1] = poison
+        with pytest.raises(rta.RtError, match="pair walk"):
+            rta.collapse_quads(bad, root, tris)
+    bad = pairs.copy()
+    bad[child]["lmin"][2], bad[child]["lmax"][2] = bad[child]["lmax"][2] + 1.0, bad[child]["lmin"][2]  # min > max
+    with pytest.raises(rta.RtError, match="pair walk"):
+        rta.collapse_quads(bad, root, tris)
+    one = pairs[:1].copy()  # a tree whose root is a leaf has nothing to collapse
+    one[0]["lref"], one[0]["rref"] = ~0, ~1
+    with pytest.raises(rta.RtError, match="pair walk"):
+        rta.collapse_quads(one, -1, tris)
+    bad = pairs.copy()
+    bad[0]["rref"] = len(pairs)
+    with pytest.raises(rta.RtError, match="out of range"):
+        rta.collapse_quads(bad, root, tris)
+    bad = pairs.copy()
+    bad[child]["lref"] = 0  # a cycle
+    with pytest.raises(rta.RtError, match="do not form a tree"):
+        rta.collapse_quads(bad, root, tris)
+
+
+def test_collapse_of_a_degenerate_chain_reports_its_stack(rta):
+    """A tree that is one long chain (every record: one leaf + one record) collapses to quads of three leaves + one quad:
+    the worst-case stack grows by up to three per quad level and is reported; beyond 96 entries the tree is refused."""
+    n = 60  # 60 chained records: within the pair walk's 64-level stack
+    tris = np.zeros(n + 1, rta.FLAT_TRI)
+    tris["tri_id"] = np.arange(n + 1, dtype=np.uint32) | np.uint32(0x80000000)
+    tris["e1"][:, 0] = 1
+    tris["e2"][:, 1] = 1
+    pairs = np.zeros(n, rta.PAIR)
+    for i in range(n):
+        lo = np.float32(i)
+        pairs[i]["lmin"], pairs[i]["lmax"] = (lo, 0, 0), (lo + 1, 1, 1)          # leaf i
+        pairs[i]["rmin"], pairs[i]["rmax"] = (lo + 1, 0, 0), (np.float32(n + 1), 1, 1)  # the rest of the chain
+        pairs[i]["lref"] = ~i
+        pairs[i]["rref"] = i + 1 if i + 1 < n else ~n
+    words, nq, qroot, need = rta.collapse_quads(pairs, 0, tris)
+    assert nq == (n + 2) // 3 and need <= 96 and need >= 2 * nq - 2
+    # every slot reachable once
+    refs = words[:nq, 10:14].view(np.int32)
+    leaf_refs = refs[(refs != REF_NONE) & ((refs & 1) == 1)]
+    assert sorted(((leaf_refs & ~3) - nq * 64) // 64) == list(range(n + 1))

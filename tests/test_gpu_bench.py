@@ -59,8 +59,10 @@ def test_bench_side_leg_on_the_hbm_bound_workload(gpu):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=500)
     assert p.returncode == 0, p.stderr[-2000:]
     j = _last_json(p.stdout)
+    assert "error" not in j["side"], j["side"]
+    two = j["side"]["instanced5m"]  # configs[4] as the legacy two-level scene
+    assert two["value"] > 0 and two["instances"] > 50 and two["roofline"]["kernel"] in ("k_closest2", "k_shadow2")
     side = j["side"]["spheres10m"]
-    assert "error" not in side, side
     assert side["value"] > 0 and side["unit"] == "Mrays/s" and side["triangles"] > 9_000_000 and "3840x2160" in side["workload"]
     r = side["roofline"]
     assert r["bound"] == "hbm" and r["kernel"] in ("k_closest", "k_shadow") and r["algorithmic"]["bytes_per_ray"] > 1000
