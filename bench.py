@@ -292,6 +292,8 @@ def main():
         # communicators over the same GPUs in one process is a combination no hardware run has vouched for, and the
         # control traffic is a few bytes.  RT_BENCH_TORCH_RCCL=1 brings torch's group back (the frame then goes through dist.reduce).
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: gloo must not depend on the host name resolving
         dist.init_process_group("gloo", rank=rank, world_size=world)
     torch_rccl = None
     if world > 1 and not rehearse and os.environ.get("RT_BENCH_TORCH_RCCL"):
