@@ -958,6 +958,10 @@ static int32_t build_quads(const rt_bvh_pair* pairs, int32_t root, std::vector<u
                 }
                 const float step = std::ldexp(1.0f, e);
                 if (!(quad_plane(255, step, org) >= top)) continue;
+                if (!std::isfinite(quad_plane(255, step, org))) { // (boxes near FLT_MAX: a decoded plane must stay a number)
+                    *ok = false;
+                    return 0;
+                }
                 bool fits = true;
                 for (int i = 0; i < n && fits; i++) {
                     // largest q with plane(q) <= min; smallest q with plane(q) >= max (plane() is non-decreasing in q)
