@@ -334,7 +334,16 @@ __device__ unsigned long long g_rt_time[16];
 #define RT_TMARK(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); tm_[i] += now_ - tprev_; tprev_ = now_; } while (0)
 #define RT_TWAIT asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
 #define RT_TFLUSH(base) do { if (__lane_id() == 0) for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_rt_time[(base) + k_], tm_[k_]); } while (0)
+// ... and, for the two-level walk, lanes per kind of leaf-turn work: [0] mesh exits, [1] mesh leaves, [2] TLAS leaves (instance
+// entries and primitive tests), [3] finished rays; pairs of {wave-level turns that had some, lanes}
+__device__ unsigned long long g_rt_stats2[16];
+#define RT_STAT2_DECL unsigned st2_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_STAT2(i, pred) do { const unsigned long long m_ = __ballot(pred); if (m_) { st2_[2 * (i)] += 1; st2_[2 * (i) + 1] += (unsigned)__popcll(m_); } } while (0)
+#define RT_STAT2_FLUSH(base) do { if (__lane_id() == 0) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&g_rt_stats2[(base) + k_], (unsigned long long)st2_[k_]); } while (0)
 #else
+#define RT_STAT2_DECL
+#define RT_STAT2(i, pred)
+#define RT_STAT2_FLUSH(base)
 #define RT_STAT_DECL
 #define RT_STAT(i, pred)
 #define RT_STAT_FLUSH(base)
@@ -1158,6 +1167,8 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
         sp--;
         return sp < RT_SHORT_STACK ? (int)lds[sp * RT_TRAV_BLOCK] : spill[sp - RT_SHORT_STACK];
     };
+    RT_STAT_DECL
+    RT_STAT2_DECL
     QueueShare qs = queue_open(counts, cursors, n_shards, shard_cap, sc.wave_min_rays, sc.fetch_chunk);
     for (;;) {
         if (queue_has_more(qs) && __popcll(__ballot(cur == RT_CUR_DONE)) >= sc.refill_min) {
@@ -1180,9 +1191,12 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
             wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull;
         }
         if (__ballot(cur != RT_CUR_DONE) == 0ull) break;
+        RT_STAT(3, cur != RT_CUR_DONE);
 
 #pragma unroll
         for (int rep = 0; rep < RT_CLOSEST_STEPS; rep++) { // inner nodes of either level (Scene.cpp:47-68 / Object.h:322-343)
+            RT_STAT(0, cur >= 0);
+            RT_STAT(2, cur >= 0 && cur < top_bytes);
             if (cur >= 0) {
                 f4 q0, q1, q2;
                 int lref, rref;
@@ -1207,6 +1221,11 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
 
         const unsigned long long at_leaf = __ballot(cur < 0 && cur != RT_CUR_DONE);
         if (__popcll(at_leaf) < sc.leaf_min && __ballot(cur >= 0) != 0ull) continue;
+        RT_STAT(1, cur < 0 && cur != RT_CUR_DONE);
+        RT_STAT2(0, cur == RT_CUR_EXIT);
+        RT_STAT2(1, cur < 0 && cur > RT_CUR_EXIT && in_inst >= 0);
+        RT_STAT2(2, cur < 0 && cur > RT_CUR_EXIT && in_inst < 0);
+        RT_STAT2(3, cur == RT_CUR_FINISH);
         if (cur < 0 && cur != RT_CUR_DONE) {
             if (cur == RT_CUR_EXIT) { // the mesh is finished: the world ray comes back (Object.h:384 returns)
                 const float4 o4 = q_o[q], d4 = q_d[q];
@@ -1289,7 +1308,8 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
         } else {
             wave_exact = __ballot(exact && cur != RT_CUR_DONE) != 0ull; // (lanes of this wave may have changed their ray above)
         }
-    }
+    }    RT_STAT_FLUSH(ANY ? 8 : 0);
+    RT_STAT2_FLUSH(ANY ? 8 : 0);
 }
 
 // ---------------------------------------------------------------- shading

@@ -1842,6 +1842,13 @@ int rt_debug_lane_stats(unsigned long long* out16) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_rt_stats), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
     return RT_OK;
 }
+// two-level walks: lanes per kind of leaf-turn work ([0..7] closest, [8..15] occlusion; rt_device.h, g_rt_stats2)
+int rt_debug_lane_stats2(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rt_stats2), 16 * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;
+    unsigned long long zero[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_rt_stats2), zero, sizeof(zero)) != hipSuccess) return RT_ERR_HIP;
+    return RT_OK;
+}
 // where the walks' wave cycles went ([0..7] closest, [8..15] occlusion; sections: rt_device.h, g_rt_time)
 int rt_debug_walk_times(unsigned long long* out16) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rt_time), 16 * sizeof(unsigned long long)) != hipSuccess) return RT_ERR_HIP;

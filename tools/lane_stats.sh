@@ -3,5 +3,5 @@
 set -e
 cp raytracing_amd/librt_hip.so /tmp/librt_hip_keep.so
 cp build/librt_hip_stats.so raytracing_amd/librt_hip.so
-timeout -k 10 200 python3 tools/lane_stats.py "$@" || true
+timeout -k 10 200 python3 ${LS_SCRIPT:-tools/lane_stats.py} "$@" || true
 cp /tmp/librt_hip_keep.so raytracing_amd/librt_hip.so
