@@ -96,3 +96,25 @@ def test_quad_walk_renders_the_same_frame(rta, gpu):
         frames.append((img, st["rays_shadow"]))
     assert frames[0][1] == frames[1][1]
     assert np.array_equal(frames[0][0], frames[1][0])
+
+
+def test_quad_walk_equals_the_pair_walk_at_scale(rta, gpu):
+    """BASELINE configs[2] geometry (1 000 000 random triangles: the tree is far beyond the LDS copy and the L2): two million
+    segments, the quad walk's flags against the pair walk's (which the other suites hold against the oracle)."""
+    scs = []
+    for quads in (False, True):
+        if quads:
+            os.environ["RT_TUNE_QUADS"] = "1"
+        try:
+            sc = scenes.random_triangles(rta, 1_000_000)
+            sc.build()
+            sc.upload(gpu)
+        finally:
+            os.environ.pop("RT_TUNE_QUADS", None)
+        assert (sc.quad_records() > 0) == quads
+        scs.append(sc)
+    assert 300_000 < scs[1].quad_records() < 500_000  # ~ a third of the 999 999 pair records
+    rays, tmax = _segments(2_000_000, 91, (-0.1, -0.1, -0.1), (1.1, 1.1, 1.1), 0.3)
+    a, b = scs[0].trace_any(rays, tmax), scs[1].trace_any(rays, tmax)
+    assert np.array_equal(a, b), np.count_nonzero(a != b)
+    assert 0.01 < a.mean() < 0.99, a.mean()  # both outcomes are well represented
