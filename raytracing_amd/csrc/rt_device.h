@@ -354,25 +354,39 @@ __device__ unsigned long long g_rt_stats2[16];
 #endif
 
 // Ray hand-out of the persistent traversal waves.  A queue is n_shards dense sub-queues (shard s = entries
-// [s*shard_cap, s*shard_cap + counts[s])) and every shard has its own fetch cursor; wave g works on shard g % n_shards
+// [s*shard_cap, s*shard_cap + counts[s]); shard_cap == 0: one dense array dealt out in chunks, see dealt_count) and every
+// shard has its own fetch cursor; wave g works on shard g % n_shards
 // (the launch has a multiple of n_shards waves).  A wave with idle lanes takes the next `need` rays of its shard with
 // ONE atomic, so rays of a shard go to whichever of its waves has room: no wave is left holding a long static share
 // while others have finished.  One cursor for the whole queue would saturate (~88 same-address atomics/us on MI355X);
 // 64 shards keep every address far below that.  Rays handed to one wave are consecutive: the fetch is coalesced.
 struct QueueShare {
-    uint32_t base;     // first queue index of the shard
+    uint32_t off;      // queue index of a ray = off + its number within the shard (see `dealt`)
     uint32_t count;    // live rays in the shard
     uint32_t* cursor;  // rays of the shard handed out so far, in chunks
     uint32_t next, end; // this wave's current chunk: rays [next, end) of the shard are its to hand to its lanes
     uint32_t chunk;    // rays per cursor atomic (a multiple of 64): a returning atomic costs 1-3 us under load
+    uint32_t shard, n_shards;
+    bool dealt;        // shard_cap == 0: ONE dense array dealt out in chunks, chunk c belongs to shard c % n_shards
     bool exhausted;    // wave-uniform: the cursor has passed count
 };
+// A caller's dense array of n rays has no shards of its own.  Cutting it into n_shards consecutive pieces gives every shard
+// one region of the caller's order — of an image, say — and the shard with the expensive region finishes long after the
+// others (primary rays of cornellbox at 4K: 1.33 ms against 0.90 ms, tools/coherence_probe.py).  Dealing it out in chunks
+// gives every shard a sample of the whole array, and a wave still gets consecutive rays.  dealt_count = rays shard s owns.
+__host__ __device__ inline uint32_t dealt_count(uint64_t n, uint32_t chunk, uint32_t n_shards, uint32_t s) {
+    const uint64_t full = n / chunk, rem = n % chunk;
+    return (uint32_t)((full / n_shards + (s < full % n_shards ? 1u : 0u)) * chunk + (s == full % n_shards ? rem : 0u));
+}
 RT_DEV QueueShare queue_open(const uint32_t* __restrict__ counts, uint32_t* __restrict__ cursors, uint32_t n_shards, uint32_t shard_cap,
                              int wave_min_rays, int fetch_chunk) {
     const uint32_t gwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (RT_TRAV_BLOCK / 64) + threadIdx.x / 64));
     const uint32_t shard = gwave % n_shards;
     QueueShare qs;
-    qs.base = shard * shard_cap;
+    qs.off = shard * shard_cap;
+    qs.shard = shard;
+    qs.n_shards = n_shards;
+    qs.dealt = shard_cap == 0u;
     qs.count = counts[(size_t)shard * RT_CSTRIDE];
     qs.cursor = cursors + (size_t)shard * RT_CSTRIDE;
     qs.next = qs.end = 0;
@@ -396,11 +410,12 @@ RT_DEV bool queue_fetch(QueueShare& qs, bool want, uint32_t* idx) {
         qs.next = first < qs.count ? first : qs.count;
         qs.end = first + qs.chunk < qs.count ? first + qs.chunk : qs.count;
         if (first + qs.chunk >= qs.count) qs.exhausted = true;
+        if (qs.dealt) qs.off = (first / qs.chunk * qs.n_shards + qs.shard) * qs.chunk - first; // wave-uniform; first is a multiple of chunk
     }
     const uint32_t i = qs.next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
     const bool got = want && i < qs.end;
     qs.next = qs.next + need < qs.end ? qs.next + need : qs.end;
-    *idx = qs.base + i;
+    *idx = qs.off + i;
     return got;
 }
 

@@ -81,8 +81,8 @@ struct Wave {
     float4* s_c;      // direct contribution of this ray (before throughput), path id + 1 (bits) on a path's FIRST ray else 0
     float4* s_T;      // first ray only: throughput before this bounce's scatter, number of rays of the path (bits)
     uint8_t* vis;     // 1 = shadow ray unoccluded, written by k_shadow at the ray's position
-    // counters: [b*S + s] live rays of shard s entering bounce b (bounce 0: shard s = the s-th shard_cap entries of the
-    // dense camera-ray queue), [64*S + b*S + s] shadow rays of shard s made at bounce b
+    // counters: [b*S + s] live rays of shard s entering bounce b (bounce 0: k_generate deals the camera rays round the shards in groups of RT_BLOCK,
+    // as the shading kernels do for later bounces), [64*S + b*S + s] shadow rays of shard s made at bounce b
     // Counter i lives at word i * RT_CSTRIDE (one 128-byte line each).
     uint32_t* counts;
     uint32_t* cursors; // same layout: rays of that queue shard handed out to traversal waves so far
@@ -130,23 +130,29 @@ RT_DEV void pixel_of(const PassParams& pp, int pix, int* x, int* y) {
     *y = t.y + local / t.z;
 }
 
+// Camera rays.  Path p = (sample p / npix of the pass, pixel p % npix) is written to queue entry
+//   shard * shard_cap + j * RT_BLOCK + lane,   (shard, j) = (group % n_shards, group / n_shards),   group = p / RT_BLOCK:
+// the groups of RT_BLOCK consecutive paths go round the shards, as the entries the shading kernels write for later bounces do.
+// (Shard s = the s-th consecutive piece of the dense array made every shard a band of the image; the band with the expensive
+// pixels finished long after the others.)  A wave still gets 64 neighbouring pixels of one sample.
 __global__ __launch_bounds__(RT_BLOCK) void k_generate(Wave w, PassParams pp) {
     const int p = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if ((uint32_t)p < pp.n_shards) {
+        const uint32_t groups = (uint32_t)pp.cap / RT_BLOCK, rem = (uint32_t)pp.cap % RT_BLOCK, s = (uint32_t)p;
+        w.counts[(size_t)p * RT_CSTRIDE] = (groups / pp.n_shards + (s < groups % pp.n_shards ? 1u : 0u)) * RT_BLOCK + (s == groups % pp.n_shards ? rem : 0u);
+    }
     if (p >= pp.cap) return;
+    const uint32_t q = (blockIdx.x % pp.n_shards) * pp.shard_cap + (blockIdx.x / pp.n_shards) * RT_BLOCK + threadIdx.x;
     const int s_local = p / pp.npix, pix = p - s_local * pp.npix;
     int x, y;
     pixel_of(pp, pix, &x, &y);
     V3 o, d;
     camera_ray(pp.cam, x, y, (uint32_t)(pp.spp_first + s_local), pp.spp_total, &o, &d);
-    w.q_o[0][p] = pack(o, __int_as_float(p));
-    w.q_d[0][p] = pack(d, __int_as_float(0));
-    w.q_T[0][p] = make_float4(1.f, 1.f, 1.f, 1.f);
-    w.q_p[0][p] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rng_key((uint32_t)(y * pp.width + x), (uint32_t)(pp.spp_first + s_local), pp.seed)));
+    w.q_o[0][q] = pack(o, __int_as_float(p));
+    w.q_d[0][q] = pack(d, __int_as_float(0));
+    w.q_T[0][q] = make_float4(1.f, 1.f, 1.f, 1.f);
+    w.q_p[0][q] = make_float4(0.f, 0.f, 0.f, __uint_as_float(rng_key((uint32_t)(y * pp.width + x), (uint32_t)(pp.spp_first + s_local), pp.seed)));
     w.rad[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((uint32_t)p < pp.n_shards) { // the dense camera-ray queue, cut into n_shards pieces for the traversal waves
-        const int64_t left = (int64_t)pp.cap - (int64_t)p * pp.shard_cap;
-        w.counts[(size_t)p * RT_CSTRIDE] = (uint32_t)(left < 0 ? 0 : (left > (int64_t)pp.shard_cap ? (int64_t)pp.shard_cap : left));
-    }
 }
 
 // Copies the first RT_TOP_PAIRS child-pair records into LDS (whole workgroup), as the four part arrays load_pair reads,
@@ -279,24 +285,6 @@ RT_DEV uint32_t wave_reserve(uint32_t per_lane, bool extra, uint32_t* counter) {
     if ((int)lane == leader && total) base = atomicAdd(counter, total);
     base = __shfl(base, leader);
     return base + before;
-}
-
-// Queue index -> is this entry live?  (uniform per workgroup: shard_cap is a multiple of RT_BLOCK)
-RT_DEV bool queue_entry_live(const Wave& w, const PassParams& pp, int bounce, uint32_t q, bool* block_idle) {
-    const uint32_t bq = blockIdx.x * RT_BLOCK;
-    if (bounce == 0) { // dense: entries [0, cap)
-        *block_idle = bq >= (uint32_t)pp.cap;
-        return q < (uint32_t)pp.cap;
-    }
-    const uint32_t shard = bq / pp.shard_cap;
-    if (shard >= pp.n_shards) {
-        *block_idle = true;
-        return false;
-    }
-    const uint32_t live = w.counts[(size_t)((uint32_t)bounce * pp.n_shards + shard) * RT_CSTRIDE];
-    const uint32_t local0 = bq - shard * pp.shard_cap;
-    *block_idle = local0 >= live;
-    return q - shard * pp.shard_cap < live;
 }
 
 #ifdef RT_STATS // section timing of k_shade (debug builds only): cycles and lanes per section, spread over 256 rows
@@ -700,12 +688,11 @@ static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
 
 // rt_ray[n] (24-byte records, device memory) -> the walk's two float4 streams; the first RT_SHARDS threads also set the
 // shard counters and clear the fetch cursors (the array keeps the previous call's contents).
-__global__ __launch_bounds__(RT_BLOCK) void k_stage_rays(const float* __restrict__ rays, int64_t n, int64_t piece, float4* __restrict__ o,
+__global__ __launch_bounds__(RT_BLOCK) void k_stage_rays(const float* __restrict__ rays, int64_t n, uint32_t chunk, float4* __restrict__ o,
                                                          float4* __restrict__ d, uint32_t* __restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i < RT_SHARDS) {
-        const int64_t left = n - i * piece;
-        counts[(size_t)i * RT_CSTRIDE] = (uint32_t)(left < 0 ? 0 : (left > piece ? piece : left));
+        counts[(size_t)i * RT_CSTRIDE] = dealt_count((uint64_t)n, chunk, RT_SHARDS, (uint32_t)i);
         counts[(size_t)(RT_SHARDS + i) * RT_CSTRIDE] = 0u;
     }
     if (i >= n) return;
@@ -1450,10 +1437,10 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
     TRY(hipMalloc((void**)&d_count, 2 * RT_SHARDS * RT_CSTRIDE * sizeof(uint32_t)));
     TRY(hipMemcpyAsync(d_o, o.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
     TRY(hipMemcpyAsync(d_d, d.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-    // the caller's array is cut into RT_SHARDS consecutive pieces, each with its own fetch cursor (rt_device.h, QueueShare)
-    const int64_t piece = ((n + RT_SHARDS - 1) / RT_SHARDS + 63) / 64 * 64;
+    // the caller's array is dealt out to RT_SHARDS shards in chunks, each shard with its own fetch cursor (rt_device.h, dealt_count)
+    const int64_t piece = 0; // shard_cap == 0: dealt
     std::vector<uint32_t> n32((size_t)2 * RT_SHARDS * RT_CSTRIDE, 0u); // counts, then cursors
-    for (int64_t sh = 0; sh < RT_SHARDS; sh++) n32[(size_t)sh * RT_CSTRIDE] = (uint32_t)std::max<int64_t>(0, std::min<int64_t>(piece, n - sh * piece));
+    for (int64_t sh = 0; sh < RT_SHARDS; sh++) n32[(size_t)sh * RT_CSTRIDE] = dealt_count((uint64_t)n, (uint32_t)s->view.fetch_chunk, RT_SHARDS, (uint32_t)sh);
     TRY(hipMemcpyAsync(d_count, n32.data(), n32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
     const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK; // workgroups per RT_SHARDS waves
     const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
@@ -1543,10 +1530,10 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit*
     float4* d_o = (float4*)(s->scratch_ptr + RT_NOALLOC_COUNT_BYTES);
     float4* d_d = d_o + RT_NOALLOC_MAX_RAYS;
     float4* d_hit2 = d_d + RT_NOALLOC_MAX_RAYS;
-    const int64_t piece = ((n + RT_SHARDS - 1) / RT_SHARDS + 63) / 64 * 64;
+    const int64_t piece = 0; // shard_cap == 0: the array is dealt out in chunks (rt_device.h, dealt_count)
     const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK;
     const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
-    hipLaunchKernelGGL(k_stage_rays, dim3(blocks_for(std::max<int64_t>(n, RT_SHARDS))), dim3(RT_BLOCK), 0, s->stream, (const float*)rays, n, piece, d_o, d_d, d_count);
+    hipLaunchKernelGGL(k_stage_rays, dim3(blocks_for(std::max<int64_t>(n, RT_SHARDS))), dim3(RT_BLOCK), 0, s->stream, (const float*)rays, n, (uint32_t)s->view.fetch_chunk, d_o, d_d, d_count);
     if (s->view.inst_q)
         hipLaunchKernelGGL(k_closest2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                            (uint32_t)RT_SHARDS, (uint32_t)piece, (float4*)hits, d_hit2, 1);

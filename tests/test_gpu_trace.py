@@ -113,6 +113,30 @@ def test_edge_cases(rta, orc, gpu):
     assert np.array_equal(room.trace_any(rays, tmax), orc.any_hit(oroom, rays, tmax))
 
 
+@pytest.mark.parametrize("chunk", [None, 192])
+def test_ragged_ray_counts_every_ray_gets_its_own_answer(rta, orc, gpu, chunk):
+    """rt_trace_* deal the caller's array out to the 64 queue shards in chunks of RT_TUNE_FETCH_CHUNK rays (default 128; 192: not a
+    power of two): counts around one chunk, one round of chunks (64 x 128 = 8192) and several rounds, each against the oracle."""
+    import os
+    if chunk:
+        os.environ["RT_TUNE_FETCH_CHUNK"] = str(chunk)
+    try:
+        sc = scenes.quad_room(rta)
+        sc.build()
+        sc.upload(gpu)
+    finally:
+        os.environ.pop("RT_TUNE_FETCH_CHUNK", None)
+    osc = orc.scene_from_host(sc, own_bvh=True)
+    rays = scenes.random_rays(40_000, 21, lo=(-1, 0, -1), hi=(1, 2, 1))
+    tmax = (np.random.default_rng(22).random(len(rays)) * 2.5).astype(np.float32)
+    want, _ = orc.closest_hit(osc, rays)
+    want_any = orc.any_hit(osc, rays, tmax)
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 191, 192, 193, 8191, 8192, 8193, 12288, 12289, 24575, 33000, 40_000):
+        got = sc.trace_closest(rays[:n])
+        assert got.tobytes() == want[:n].tobytes(), n
+        assert np.array_equal(sc.trace_any(rays[:n], tmax[:n]), want_any[:n]), n
+
+
 def test_host_scene_api(rta, orc, room):
     """Scene::closest_hit / Scene::any_hit (the reference's query seam) for single rays."""
     sc, osc = room
