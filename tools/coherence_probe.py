@@ -5,7 +5,8 @@ each traced in (a) path order (the order the renderer's queues have: children wh
 (c) sorted by direction octant + 30-bit Morton code of the origin, (d) sorted by a coarse key (octant + 4x4x4 origin cell: what a
 one-pass binning by the shading kernels could produce), (e) 256-ray blocks shuffled, (f) shuffled within windows of 4096.  Run under `rocprofv3 --kernel-trace --stats`: the script prints the order of
 its launches, tools/coherence_report.py pairs them with the trace's durations.
-usage: tools/coherence_probe.py [width height]"""
+usage: tools/coherence_probe.py [width height [cornellbox|spheres10m]]  (spheres10m: the 9.6 M-triangle field, shadow segments
+towards the sky — cosine-distributed directions, no end)"""
 import os
 import sys
 
@@ -21,10 +22,17 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 1920
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 1080
 rng = np.random.default_rng(11)
 
-sc = scenes.cornellbox(rta)
-sc.build(max_per_leaf=2)
-sc.upload(0)
-info = sc.info()
+WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "cornellbox"
+if WORKLOAD == "spheres10m":
+    sc = scenes.sphere_field(rta)
+    sc.build(max_per_leaf=2)
+    sc.upload(0)
+    info = {"camera_view": rta.look_at((0.5, 0.5, 2.6), (0.5, 0.5, 0.5), (0, 1, 0)), "camera_fov": 39.6}
+else:
+    sc = scenes.cornellbox(rta)
+    sc.build(max_per_leaf=2)
+    sc.upload(0)
+    info = sc.info()
 verts, tris = sc.array(rta.ARR_VERTS), sc.array(rta.ARR_TRIS)
 p0, p1, p2 = (verts["pos"][tris["idx"][:, k]].astype(np.float64) for k in range(3))
 gn = np.cross(p1 - p0, p2 - p0)
@@ -122,10 +130,14 @@ for b in range(3):
                        rng.uniform(-0.5, 0.5, len(nxt)) * (hi[2] - lo[2]) * 0.3 + (lo[2] + hi[2]) / 2], 1)
     seg = np.zeros(len(nxt), rta.RAY)
     seg["o"] = nxt["o"]
-    dv = target - nxt["o"].astype(np.float64)
-    dist = np.linalg.norm(dv, axis=1)
-    seg["d"] = (dv / dist[:, None]).astype(np.float32)
-    tmax = (dist - 1e-3).astype(np.float32)
+    if WORKLOAD == "spheres10m":
+        seg["d"] = bounce(rays, ref)["d"]  # another cosine-distributed direction from the same points
+        tmax = np.full(len(nxt), np.inf, np.float32)
+    else:
+        dv = target - nxt["o"].astype(np.float64)
+        dist = np.linalg.norm(dv, axis=1)
+        seg["d"] = (dv / dist[:, None]).astype(np.float32)
+        tmax = (dist - 1e-3).astype(np.float32)
     ref_any = None
     for name, perm in orders(seg).items():
         occ = sc.trace_any(seg[perm], tmax[perm])
