@@ -686,10 +686,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_resolve(const float* __restrict__ 
 #define RT_NOALLOC_BYTES ((size_t)RT_NOALLOC_COUNT_BYTES + (size_t)3 * 16 * RT_NOALLOC_MAX_RAYS)
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_BYTES];
 
-// rt_ray[n] (24-byte records, device memory) -> the walk's two float4 streams; the first RT_SHARDS threads also set the
+// rt_ray[n] (24-byte records, device memory) [+ tmax[n]] -> the walk's two float4 streams; the first RT_SHARDS threads also set the
 // shard counters and clear the fetch cursors (the array keeps the previous call's contents).
-__global__ __launch_bounds__(RT_BLOCK) void k_stage_rays(const float* __restrict__ rays, int64_t n, uint32_t chunk, float4* __restrict__ o,
-                                                         float4* __restrict__ d, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(RT_BLOCK) void k_stage_rays(const float* __restrict__ rays, const float* __restrict__ tmax, int64_t n, uint32_t chunk,
+                                                         float4* __restrict__ o, float4* __restrict__ d, uint32_t* __restrict__ counts) {
     const int64_t i = (int64_t)blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i < RT_SHARDS) {
         counts[(size_t)i * RT_CSTRIDE] = dealt_count((uint64_t)n, chunk, RT_SHARDS, (uint32_t)i);
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_stage_rays(const float* __restrict
     }
     if (i >= n) return;
     const float* r = rays + 6 * i;
-    o[i] = make_float4(r[0], r[1], r[2], INFINITY);
+    o[i] = make_float4(r[0], r[1], r[2], tmax ? tmax[i] : INFINITY);
     d[i] = make_float4(r[3], r[4], r[5], 0.f);
 }
 
@@ -737,6 +737,8 @@ struct rt_scene {
     // checked nor uploaded again)
     int4* d_tiles = nullptr;
     size_t d_tiles_cap = 0;
+    unsigned char* api_mem = nullptr; // rt_trace_*'s device buffers: one allocation, grown on demand, kept up to RT_API_KEEP_BYTES
+    size_t api_cap = 0;
     std::vector<int32_t> tiles_host; // x0, y0, x1, y1 per tile, as the caller gave them
     int64_t tiles_npix = 0;
     int32_t tiles_w = 0, tiles_h = 0; // raster the cached list was checked against
@@ -1347,6 +1349,7 @@ void rt_scene_destroy(rt_scene* s) {
     for (void* p : s->owned) (void)hipFree(p);
     if (s->d_sum) (void)hipFree(s->d_sum);
     if (s->d_tiles) (void)hipFree(s->d_tiles);
+    if (s->api_mem) (void)hipFree(s->api_mem);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     for (hipEvent_t e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
@@ -1401,28 +1404,53 @@ int rt_scene_sync(rt_scene* s) {
     return RT_OK;
 }
 
+#define RT_API_KEEP_BYTES ((size_t)1 << 30)
 static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int64_t n, rt_hit* hits, uint8_t* occ, int32_t* index = nullptr) {
     if (!s || !rays || n < 0 || (!hits && !occ)) return fail(RT_ERR_INVALID, "rt_trace: bad argument");
     if (n == 0) return RT_OK;
     if (n > 0x7fffffff) return fail(RT_ERR_LIMIT, "rt_trace: more than 2^31-1 rays in one call");
     HIPCHK(hipSetDevice(s->device));
-    std::vector<float4> o((size_t)n), d((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        o[i] = make_float4(rays[i].o[0], rays[i].o[1], rays[i].o[2], tmax ? tmax[i] : INFINITY);
-        d[i] = make_float4(rays[i].d[0], rays[i].d[1], rays[i].d[2], 0.f);
-    }
-    float4 *d_o = nullptr, *d_d = nullptr, *d_hit = nullptr, *d_hit2 = nullptr;
-    uint8_t* d_occ = nullptr;
+    // The caller's records go to the device as they are (24-byte rays, 4-byte segment ends) and are put into the walk's two float4
+    // streams there; hits come back straight into the caller's array (rt_hit is the kernels' 16-byte record).  No host loop over rays.
+    static_assert(sizeof(rt_ray) == 24 && sizeof(rt_hit) == 16, "rt_ray / rt_hit are copied as raw records");
     const bool two_level = s->view.inst_q != nullptr;
-    uint32_t* d_count = nullptr;
     int rc = RT_OK;
+    // One device allocation holds every buffer of the call; it stays with the scene for the next call (a query of a few rays costs a
+    // launch, not seven hipMalloc / hipFree pairs) unless it is larger than RT_API_KEEP_BYTES.
+    const size_t sz_count = 2 * RT_SHARDS * RT_CSTRIDE * sizeof(uint32_t), sz4 = ((size_t)n * sizeof(float4) + 255) & ~(size_t)255;
+    const size_t sz_rays = ((size_t)n * sizeof(rt_ray) + 255) & ~(size_t)255, sz_f = ((size_t)n * sizeof(float) + 255) & ~(size_t)255;
+    const size_t sz_b = ((size_t)n + 255) & ~(size_t)255;
+    const size_t need = sz_count + sz_rays + (tmax ? sz_f : 0) + 2 * sz4 + (hits ? sz4 * (two_level ? 2 : 1) : sz_b);
+    if (s->api_cap < need) {
+        if (s->api_mem) (void)hipFree(s->api_mem);
+        s->api_mem = nullptr;
+        s->api_cap = 0;
+        if (hipMalloc((void**)&s->api_mem, need) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(RT_ERR_HIP, "rt_trace: out of device memory for " + std::to_string(n) + " rays");
+        }
+        s->api_cap = need;
+    }
+    unsigned char* at = s->api_mem;
+    auto take = [&](size_t bytes) {
+        unsigned char* p = at;
+        at += bytes;
+        return p;
+    };
+    uint32_t* d_count = (uint32_t*)take(sz_count);
+    float* d_rays = (float*)take(sz_rays);
+    float* d_tmax = tmax ? (float*)take(sz_f) : nullptr;
+    float4 *d_o = (float4*)take(sz4), *d_d = (float4*)take(sz4);
+    float4* d_hit = hits ? (float4*)take(sz4) : nullptr;
+    float4* d_hit2 = hits && two_level ? (float4*)take(sz4) : nullptr;
+    uint8_t* d_occ = hits ? nullptr : (uint8_t*)take(sz_b);
     auto cleanup = [&]() {
-        (void)hipFree(d_o);
-        (void)hipFree(d_d);
-        (void)hipFree(d_hit);
-        (void)hipFree(d_hit2);
-        (void)hipFree(d_occ);
-        (void)hipFree(d_count);
+        if (s->api_cap > RT_API_KEEP_BYTES) {
+            (void)hipStreamSynchronize(s->stream);
+            (void)hipFree(s->api_mem);
+            s->api_mem = nullptr;
+            s->api_cap = 0;
+        }
     };
 #define TRY(expr)                                                                  \
     do {                                                                           \
@@ -1432,53 +1460,44 @@ static int trace_common(rt_scene* s, const rt_ray* rays, const float* tmax, int6
             return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
         }                                                                          \
     } while (0)
-    TRY(hipMalloc((void**)&d_o, (size_t)n * sizeof(float4)));
-    TRY(hipMalloc((void**)&d_d, (size_t)n * sizeof(float4)));
-    TRY(hipMalloc((void**)&d_count, 2 * RT_SHARDS * RT_CSTRIDE * sizeof(uint32_t)));
-    TRY(hipMemcpyAsync(d_o, o.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-    TRY(hipMemcpyAsync(d_d, d.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, s->stream));
-    // the caller's array is dealt out to RT_SHARDS shards in chunks, each shard with its own fetch cursor (rt_device.h, dealt_count)
+    TRY(hipMemcpyAsync(d_rays, rays, (size_t)n * sizeof(rt_ray), hipMemcpyHostToDevice, s->stream));
+    if (tmax) TRY(hipMemcpyAsync(d_tmax, tmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    // the caller's array is dealt out to RT_SHARDS shards in chunks, each shard with its own fetch cursor (rt_device.h, dealt_count);
+    // k_stage_rays sets the shard counts and clears the cursors
     const int64_t piece = 0; // shard_cap == 0: dealt
-    std::vector<uint32_t> n32((size_t)2 * RT_SHARDS * RT_CSTRIDE, 0u); // counts, then cursors
-    for (int64_t sh = 0; sh < RT_SHARDS; sh++) n32[(size_t)sh * RT_CSTRIDE] = dealt_count((uint64_t)n, (uint32_t)s->view.fetch_chunk, RT_SHARDS, (uint32_t)sh);
-    TRY(hipMemcpyAsync(d_count, n32.data(), n32.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    hipLaunchKernelGGL(k_stage_rays, dim3(blocks_for(std::max<int64_t>(n, RT_SHARDS))), dim3(RT_BLOCK), 0, s->stream, (const float*)d_rays, (const float*)d_tmax, n,
+                       (uint32_t)s->view.fetch_chunk, d_o, d_d, d_count);
+    TRY(hipGetLastError());
     const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK; // workgroups per RT_SHARDS waves
     const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
     if (hits) {
-        TRY(hipMalloc((void**)&d_hit, (size_t)n * sizeof(float4)));
-        std::vector<float4> h((size_t)n), h2;
+        std::vector<float4> h2;
         if (two_level) {
-            TRY(hipMalloc((void**)&d_hit2, (size_t)n * sizeof(float4)));
             hipLaunchKernelGGL(k_closest2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, d_hit2, 1);
             TRY(hipGetLastError());
-            h2.resize((size_t)n);
-            TRY(hipMemcpyAsync(h2.data(), d_hit2, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+            if (index) {
+                h2.resize((size_t)n);
+                TRY(hipMemcpyAsync(h2.data(), d_hit2, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+            }
         } else {
             hipLaunchKernelGGL(k_closest, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_hit, 1);
             TRY(hipGetLastError());
         }
-        TRY(hipMemcpyAsync(h.data(), d_hit, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        TRY(hipMemcpyAsync(hits, d_hit, (size_t)n * sizeof(rt_hit), hipMemcpyDeviceToHost, s->stream));
         TRY(hipStreamSynchronize(s->stream));
-        for (int64_t i = 0; i < n; i++) {
-            int32_t tri;
-            std::memcpy(&tri, &h[i].x, 4);
-            hits[i].tri = tri;
-            hits[i].t = h[i].y;
-            hits[i].u = h[i].z;
-            hits[i].v = h[i].w;
-            if (index) {
-                int32_t iw = tri < 0 ? -1 : 0;
+        if (index) {
+            for (int64_t i = 0; i < n; i++) {
+                int32_t iw = hits[i].tri < 0 ? -1 : 0;
                 if (two_level) {
-                    std::memcpy(&iw, &h2[i].w, 4);
+                    std::memcpy(&iw, &h2[(size_t)i].w, 4);
                     if (iw >= 0) iw &= RT_HIT2_FRONT - 1;
                 }
                 index[i] = iw;
             }
         }
     } else {
-        TRY(hipMalloc((void**)&d_occ, (size_t)n));
         if (two_level)
             hipLaunchKernelGGL(k_shadow2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                                (uint32_t)RT_SHARDS, (uint32_t)piece, d_occ, 1);
@@ -1533,7 +1552,7 @@ int rt_trace_closest_noalloc(rt_scene* s, const rt_ray* rays, int64_t n, rt_hit*
     const int64_t piece = 0; // shard_cap == 0: the array is dealt out in chunks (rt_device.h, dealt_count)
     const unsigned wg_unit = RT_SHARDS * 64 / RT_TRAV_BLOCK;
     const unsigned grid = std::min(((unsigned)((n + RT_TRAV_BLOCK - 1) / RT_TRAV_BLOCK) + wg_unit - 1) / wg_unit * wg_unit, s->persistent_blocks);
-    hipLaunchKernelGGL(k_stage_rays, dim3(blocks_for(std::max<int64_t>(n, RT_SHARDS))), dim3(RT_BLOCK), 0, s->stream, (const float*)rays, n, (uint32_t)s->view.fetch_chunk, d_o, d_d, d_count);
+    hipLaunchKernelGGL(k_stage_rays, dim3(blocks_for(std::max<int64_t>(n, RT_SHARDS))), dim3(RT_BLOCK), 0, s->stream, (const float*)rays, (const float*)nullptr, n, (uint32_t)s->view.fetch_chunk, d_o, d_d, d_count);
     if (s->view.inst_q)
         hipLaunchKernelGGL(k_closest2, dim3(grid), dim3(RT_TRAV_BLOCK), 0, s->stream, s->view, d_o, d_d, d_count, d_count + RT_SHARDS * RT_CSTRIDE,
                            (uint32_t)RT_SHARDS, (uint32_t)piece, (float4*)hits, d_hit2, 1);
