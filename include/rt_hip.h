@@ -274,7 +274,9 @@ int rt_scene_create_instanced(const rt_scene_desc* geometry, const rt_tlas_desc*
 
 /* Replaces bool Scene::closest_hit(Ray, Intersection*) const
  * (Scene.cpp:17-77 over TriangleMesh::intersect, Object.h:273-357) for a
- * batch of n rays; host pointers. */
+ * batch of n rays; host pointers.  The records are copied to the device as they are and laid out there; results return
+ * straight into `hits`.  The scene keeps one device allocation for these calls (grown on demand, kept up to 1 GiB):
+ * calls on one scene must not overlap. */
 int rt_trace_closest(rt_scene* scene, const rt_ray* rays, int64_t n, rt_hit* hits);
 
 /* The same with Intersection::index (Scene.cpp:42): index[i] = instance hit, -1 on a miss (0 on a hit in a scene without
