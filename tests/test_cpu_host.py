@@ -87,6 +87,32 @@ def test_threaded_build_other_leaf_sizes_is_bit_identical(rta, orc, monkeypatch,
     assert sn.tobytes() == hn.tobytes() and np.array_equal(si, hi)
 
 
+@pytest.mark.parametrize("leaf,flat", [(1, False), (2, True)])
+def test_binned_sah_costs_equal_the_sweep_bit_for_bit(rta, orc, monkeypatch, leaf, flat):
+    """The host builder gets all 300 candidate costs of a node from one binning pass (unions are min / max, counts integers: exact),
+    with several threads binning one large range; the oracle sweeps every candidate over every primitive as the reference does
+    (BVH.cpp:30-46).  140 000 boxes — enough for two binning threads at the root — with coincident boxes, signed zeros, many equal
+    centres on plane values, and optionally one flat axis (lo == hi: no candidates on it): same nodes, same indices."""
+    n = 140_000
+    b = _random_bounds(n, 1234 + leaf, False)
+    b[5000:5600] = b[5000]
+    grid = (np.arange(3000) % 101).astype(np.float32) / 100.0  # centres that sit exactly on candidate planes of the root
+    b[10_000:13_000, 0] = grid - 0.01
+    b[10_000:13_000, 3] = grid + 0.01
+    b[20_000:20_100, 1] = -0.0
+    b[20_100:20_200, 1] = 0.0
+    if flat:
+        b[:, 2] = 0.25
+        b[:, 5] = 0.25
+    monkeypatch.setenv("RT_BVH_THREADS", "5")
+    hn, hi = rta.bvh_build(b, leaf, 1)
+    on, oi = orc.bvh_build(b, leaf, 1)
+    assert hn.tobytes() == on.tobytes() and np.array_equal(hi, oi)
+    monkeypatch.setenv("RT_BVH_THREADS", "1")
+    sn, si = rta.bvh_build(b, leaf, 1)
+    assert sn.tobytes() == hn.tobytes() and np.array_equal(si, hi)
+
+
 def test_tri_bounds_and_mesh_build(rta, orc):
     sc = scenes.quad_room(rta)
     sc.build()
