@@ -12,7 +12,7 @@
 // Costs: the reference sweeps every candidate plane over every primitive of the
 // node, O(300 n) per node — 40 s for 1 M triangles on one core.  Here all 300
 // costs of a node come from ONE binning pass (binned_costs: same values bit for
-// bit, 8.3 -> 2.2 s for 1 M random triangles on 8 threads).
+// bit, 8.3 -> 1.2 s for 1 M random triangles on 8 threads with the larger tasks below).
 //
 // Threads (BVH_SAH with one primitive per leaf, the only way the reference
 // calls it: Object.cpp:11-22):  With single-primitive leaves a subtree over n
@@ -233,7 +233,31 @@ public:
     std::vector<int> order_;
 
 private:
-    Bounds enclose(int b, int e) const {
+    // Ranges of at least this many primitives spread their gathers (boxes, centres: one cache miss each) over the threads.
+    static constexpr int kParallelRange = 262144;
+    template <class F>
+    static void for_chunks(int b, int e, int parts, F&& f) { // f(part, begin, end), the last part on the calling thread
+        std::vector<std::thread> pool;
+        const int64_t n = e - b;
+        for (int t = 0; t < parts; t++) {
+            const int tb = b + (int)(n * t / parts), te = b + (int)(n * (t + 1) / parts);
+            if (t + 1 < parts) pool.emplace_back([&f, t, tb, te]() { f(t, tb, te); });
+            else f(t, tb, te);
+        }
+        for (auto& th : pool) th.join();
+    }
+    Bounds enclose(int b, int e, int n_threads = 1) const {
+        if (n_threads > 1 && e - b >= kParallelRange) { // min / max: the same box whatever the grouping
+            std::vector<Bounds> part((size_t)n_threads);
+            for_chunks(b, e, n_threads, [&](int t, int tb, int te) {
+                Bounds box;
+                for (int i = tb; i < te; i++) box = bounds_union(box, prims_[order_[i]]);
+                part[(size_t)t] = box;
+            });
+            Bounds box;
+            for (const Bounds& p : part) box = bounds_union(box, p);
+            return box;
+        }
         Bounds box;
         for (int i = b; i < e; i++) box = bounds_union(box, prims_[order_[i]]);
         return box;
@@ -352,10 +376,31 @@ private:
         return true;
     }
 
-    int partition_at(const Range& r, int axis, float plane) {
-        auto first = order_.begin() + r.begin, last = order_.begin() + r.end;
-        auto mid = std::partition(first, last, [&](int p) { return centre_[p][axis] < plane; });
-        int split = int(mid - order_.begin());
+    int partition_at(const Range& r, int axis, float plane, int n_threads = 1) {
+        int split;
+        if (n_threads > 1 && r.end - r.begin >= kParallelRange) {
+            // std::partition's own permutation (libstdc++, bidirectional iterators: the k-th misplaced element from the front is
+            // swapped with the k-th misplaced one from the back), with the predicate — the gather — evaluated beforehand by all threads
+            std::vector<uint8_t> low((size_t)(r.end - r.begin));
+            for_chunks(r.begin, r.end, n_threads, [&](int, int tb, int te) {
+                for (int i = tb; i < te; i++) low[(size_t)(i - r.begin)] = centre_[order_[i]][axis] < plane ? 1 : 0;
+            });
+            int first = r.begin, last = r.end;
+            for (;;) {
+                while (first != last && low[(size_t)(first - r.begin)]) ++first;
+                if (first == last) break;
+                --last;
+                while (first != last && !low[(size_t)(last - r.begin)]) --last;
+                if (first == last) break;
+                std::swap(order_[first], order_[last]);
+                ++first;
+            }
+            split = first;
+        } else {
+            auto first = order_.begin() + r.begin, last = order_.begin() + r.end;
+            auto mid = std::partition(first, last, [&](int p) { return centre_[p][axis] < plane; });
+            split = int(mid - order_.begin());
+        }
         if (split == r.begin || split == r.end) split = (r.begin + r.end) / 2;
         return split;
     }
@@ -364,7 +409,7 @@ private:
     bool split_node(const Range& r, int* split, int n_threads = 1) { return split_node(nodes_, r, split, n_threads); }
     bool split_node(std::vector<BVHNode>& nodes, const Range& r, int* split, int n_threads) {
         BVHNode& node = nodes[r.node];
-        node.aabb = enclose(r.begin, r.end);
+        node.aabb = enclose(r.begin, r.end, n_threads);
         const int n = r.end - r.begin;
         if (n <= leaf_size_) {
             node.left_node = r.begin;
@@ -374,7 +419,7 @@ private:
         const Bounds box = node.aabb;
         if (how_ == BVH_MIDDLE) {
             const int axis = box.longest_axis();
-            *split = partition_at(r, axis, box.get_center()[axis]);
+            *split = partition_at(r, axis, box.get_center()[axis], n_threads);
             return true;
         }
         int best_axis = -1;
@@ -415,7 +460,7 @@ private:
         // The reference reads an uninitialised axis/plane when no plane scores
         // below 1e30 (BVH.cpp:91-97, e.g. coincident primitives).  Defined here as
         // the median split, which is also what its degenerate-partition rule gives.
-        *split = best_axis < 0 ? (r.begin + r.end) / 2 : partition_at(r, best_axis, best_plane);
+        *split = best_axis < 0 ? (r.begin + r.end) / 2 : partition_at(r, best_axis, best_plane, n_threads);
         return true;
     }
 
@@ -438,7 +483,10 @@ BVH BVH::build(const std::vector<Bounds>& bounds, int max_per_node, PartitionStr
     if (const char* e = std::getenv("OMP_NUM_THREADS")) n_threads = std::min(n_threads > 0 ? n_threads : 1, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("RT_BVH_THREADS")) n_threads = std::max(1, std::atoi(e));
     n_threads = std::max(1, std::min(n_threads, 64));
-    const int small = 16384; // primitives below which a subtree is one thread's task
+    // primitives below which a subtree is one thread's task: large tasks (the top of the tree, one node at a time, is the part that
+    // scales worst) but at least two per thread (2 M boxes on 8 threads: 4096: 4.3 s, 16384: 2.5, 65536: 2.3, 131072: 1.8)
+    int small = std::min(131072, std::max(16384, (int)(bounds.size() / (2 * (size_t)n_threads))));
+    if (const char* e = std::getenv("RT_BVH_SMALL")) small = std::max(1024, std::atoi(e));
     if (strat == BVH_SAH && max_per_node == 1 && n_threads > 1 && (int)bounds.size() > 2 * small)
         b.run_threaded(n_threads, small);
     else if (n_threads > 1 && (int)bounds.size() > 2 * small)

@@ -113,6 +113,23 @@ def test_binned_sah_costs_equal_the_sweep_bit_for_bit(rta, orc, monkeypatch, lea
     assert sn.tobytes() == hn.tobytes() and np.array_equal(si, hi)
 
 
+def test_large_ranges_gather_in_parallel_with_the_same_result(rta, orc, monkeypatch):
+    """Ranges of 262 144 primitives and more evaluate a split's predicate and a node's box on all threads and then apply
+    std::partition's own permutation: 300 000 boxes, BVH_MIDDLE against the oracle's recursion (partition + box on every level),
+    BVH_SAH several threads against one thread (which the other tests hold against the oracle)."""
+    n = 300_000
+    b = _random_bounds(n, 4321, False)
+    b[7000:7400] = b[7000]
+    monkeypatch.setenv("RT_BVH_THREADS", "5")
+    hn, hi = rta.bvh_build(b, 1, 0)
+    on, oi = orc.bvh_build(b, 1, 0)
+    assert hn.tobytes() == on.tobytes() and np.array_equal(hi, oi)
+    tn, ti = rta.bvh_build(b, 2, 1)
+    monkeypatch.setenv("RT_BVH_THREADS", "1")
+    sn, si = rta.bvh_build(b, 2, 1)
+    assert sn.tobytes() == tn.tobytes() and np.array_equal(si, ti)
+
+
 def test_tri_bounds_and_mesh_build(rta, orc):
     sc = scenes.quad_room(rta)
     sc.build()
