@@ -1024,7 +1024,8 @@ RT_DEV float comp(const V3& v, int a) { return a == 0 ? v.x : (a == 1 ? v.y : v.
 // Geometry::intersect of the analytic primitives with the ray in model space.  (o, d, tmin, tmax) as the reference
 // passes them; on a hit t, n (oriented), front, u, v are set.  Comparisons the reference writes against double
 // constants are made in double.  p = the instance's parameters (rt_instance.p).
-RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& d, float tmin, float tmax, Hit2* h) {
+template <class Store>
+RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& d, float tmin, float tmax, float* t_out, Store&& store) {
     switch (geometry) {
     case RT_GEO_SPHERE: { // Object.h:34-55
         const float radius = p[0];
@@ -1040,10 +1041,9 @@ RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& 
             if (root < tmin || root > tmax) return false;
         }
         const V3 out = (o + d * root) / radius;
-        h->t = root;
-        h->front = dot(d, out) < 0.f;
-        h->n = h->front ? out : -out;
-        h->u = h->v = 0.f;
+        const bool front = dot(d, out) < 0.f;
+        *t_out = root;
+        store(0.f, 0.f, front ? out : -out, front);
         return true;
     }
     case RT_GEO_RECTANGLE: { // Object.h:93-120
@@ -1058,11 +1058,9 @@ RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& 
         if (ud < -p[9] || ud > p[9]) return false;
         const float vd = dot(pi, B);
         if (vd < -p[10] || vd > p[10]) return false;
-        h->t = t;
-        h->front = dot(d, N) < 0.f;
-        h->n = h->front ? N : -N;
-        h->u = ud / p[9];
-        h->v = vd / p[10];
+        const bool front = dot(d, N) < 0.f;
+        *t_out = t;
+        store(ud / p[9], vd / p[10], front ? N : -N, front);
         return true;
     }
     case RT_GEO_DISK: { // Object.h:141-162
@@ -1074,10 +1072,9 @@ RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& 
         if (t < tmin || t > tmax) return false;
         const float r = len(o + d * t);
         if (r > p[3] || r < p[4]) return false;
-        h->t = t;
-        h->front = dot(d, N) < 0.f;
-        h->n = h->front ? N : -N;
-        h->u = h->v = 0.f;
+        const bool front = dot(d, N) < 0.f;
+        *t_out = t;
+        store(0.f, 0.f, front ? N : -N, front);
         return true;
     }
     case RT_GEO_BOX: { // Object.h:175-204
@@ -1097,10 +1094,9 @@ RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& 
         }
         const float s = comp(d, idx) > 0.f ? -1.f : 1.f;
         const V3 out(idx == 0 ? s : 0.f, idx == 1 ? s : 0.f, idx == 2 ? s : 0.f);
-        h->t = gm;
-        h->front = dot(d, out) < 0.f;
-        h->n = h->front ? out : -out;
-        h->u = h->v = 0.f;
+        const bool front = dot(d, out) < 0.f;
+        *t_out = gm;
+        store(0.f, 0.f, front ? out : -out, front);
         return true;
     }
     case RT_GEO_CYLINDER: { // Object.h:216-239
@@ -1119,10 +1115,8 @@ RT_DEV bool prim_intersect(int geometry, const float* p, const V3& o, const V3& 
             if (root < tmin || root > tmax || pt.y < ymin || pt.y > ymax) return false;
         }
         const V3 out = V3(pt.x, 0.f, pt.z) / radius;
-        h->t = root;
-        h->n = dot(d, out) < 0.f ? out : -out; // set_forward_face, Def.h:35-39
-        h->front = true;
-        h->u = h->v = 0.f;
+        *t_out = root;
+        store(0.f, 0.f, dot(d, out) < 0.f ? out : -out, true); // set_forward_face, Def.h:35-39
         return true;
     }
     default: return false;
@@ -1287,12 +1281,13 @@ RT_DEV void trace_queue2(const SceneView& sc, const float4* __restrict__ q_o, co
                     const float4* pq = sc.inst_p + (size_t)k * 3;
                     const float4 p0 = pq[0], p1 = pq[1], p2 = pq[2];
                     const float p[12] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-                    Hit2 g;
+                    // (the hit's record is stored where a geometry's test ends: nothing but t is carried out of the switch)
+                    float t_prim;
                     bool stop = false;
-                    if (prim_intersect(geometry, p, mo, md, 0.f, t_best, &g)) {
-                        t_best = g.t;
+                    if (prim_intersect(geometry, p, mo, md, 0.f, t_best, &t_prim,
+                                       [&](float u, float v, const V3& n, bool front) { hit_store(u, v, -2, k | (front ? 0x40000000 : 0), n); })) {
+                        t_best = t_prim;
                         found = true;
-                        hit_store(g.u, g.v, -2, k | (g.front ? 0x40000000 : 0), g.n);
                         stop = ANY;
                     }
                     cur = stop ? RT_CUR_HIT : pop();
